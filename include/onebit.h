@@ -1,0 +1,103 @@
+/*
+ * onebit.h -- C ABI of the MI355X-native OneBit 1-bit linear layer (libonebit_hip.so).
+ *
+ * The reference (xuyuzhuang11/OneBit) has no FFI or plugin registry for this
+ * path: its "operator API" is the Python nn.Module BitLinearInf
+ * (transformers/src/transformers/models/bitnet.py:71-122) plus the sign packer
+ * in scripts/convert_llama_to_infer_ckpt.py:7-15.  This header is therefore the
+ * drop-in boundary the replacement module (onebit_amd/bitnet.py) binds through
+ * ctypes; each entry point names the reference lines it replaces.  See
+ * INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (torch tensors in
+ *    practice).  The library never allocates, frees or retains them.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *    only enqueue work; they never synchronise and are graph-capture safe.
+ *  - `dtype` selects the floating type of x / h / g / bias / y: ONEBIT_F16 or
+ *    ONEBIT_F32 (the reference computes in the dtype of weight_scale,
+ *    bitnet.py:99).  Packed weights are always the reference's int8 [N, K/8]
+ *    tensor (bitnet.py:78), LSB-first, bit 1 = -1; rows may be strided
+ *    (`ldw_bytes`) so a K-shard can alias a column slice of the full matrix.
+ *  - Return value: 0 = ok; negative = argument error (ONEBIT_E_*); positive =
+ *    hipError_t from a launch.  onebit_last_error() returns a thread-local
+ *    message for the last non-zero return.
+ */
+#ifndef ONEBIT_H
+#define ONEBIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONEBIT_ABI_VERSION 1
+
+#define ONEBIT_F16 0
+#define ONEBIT_F32 1
+
+#define ONEBIT_E_ARG      (-1)   /* null pointer / negative size                        */
+#define ONEBIT_E_SHAPE    (-2)   /* K % 8 != 0                                           */
+#define ONEBIT_E_ALIGN    (-3)   /* pointer or row pitch not aligned as documented      */
+#define ONEBIT_E_DTYPE    (-4)   /* unknown dtype                                       */
+#define ONEBIT_E_WSPACE   (-5)   /* workspace too small                                 */
+#define ONEBIT_E_FLAG     (-6)   /* unknown flag                                        */
+
+/* flags for onebit_linear_forward */
+#define ONEBIT_FLAG_SKIP_LN   1u   /* y receives u = (W.(h*x))*g, LayerNorm (and bias) skipped */
+
+int onebit_abi_version(void);
+const char *onebit_last_error(void);
+
+/* ---- packing -------------------------------------------------------------
+ * onebit_pack_signs: packed = fp16_to_int8(sign(w))
+ *   replaces scripts/convert_llama_to_infer_ckpt.py:7-15 (fp16_to_int8) applied
+ *   as in :29-32; bit = (w < 0), so w == 0 and NaN pack as +1.
+ *   w [N,K] (dtype), packed int8 [N,K/8].  K % 8 == 0.
+ * onebit_unpack_signs: dense = int8_to_fp16(packed)
+ *   replaces bitnet.py:98-110.  out [N,K] (dtype) of +1 / -1.
+ */
+int onebit_pack_signs(const void *w, int dtype, void *packed, int64_t N, int64_t K, void *stream);
+int onebit_unpack_signs(const void *packed, void *out, int dtype, int64_t N, int64_t K, void *stream);
+
+/* ---- forward (bitnet.py:112-122) -------------------------------------------
+ * y[T,N] = LayerNorm_N( g * ( W(+-1) . (h * x[T,K]) ) ) (+ bias)
+ *   dtype F16: the reference's fp16 rounding points are reproduced
+ *     (a = fp16(x*h) :113; z = fp16(sum, fp32 accumulate) :115; u = fp16(z*g)
+ *     :116; LayerNorm statistics in fp32, eps, biased variance :118; bias :119).
+ *   dtype F32: everything in fp32.
+ *   K % 8 == 0 (the reference's packing constraint).  The MFMA kernels take
+ *   K % 32 == 0 with 4-byte aligned packed rows (every LLaMA shape; 16-byte
+ *   aligned rows get the widest loads); other shapes run a generic kernel.
+ *   x, y rows contiguous; x/h/y 16-byte aligned.  u_or_null, if given,
+ *   receives the pre-LayerNorm u [T,N].  workspace:
+ *   onebit_linear_workspace_bytes() bytes (0 for MFMA shapes), 16-byte
+ *   aligned, caller-owned scratch.
+ */
+size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype);
+int onebit_linear_forward(const void *packed, int64_t ldw_bytes, const void *x, const void *h,
+                          const void *g, const void *bias_or_null, void *y, void *u_or_null,
+                          void *workspace, size_t workspace_bytes, int64_t T, int64_t K,
+                          int64_t N, int dtype, float ln_eps, unsigned flags, void *stream);
+
+/* ---- split entry points (K-sharded multi-GPU path) -----
+ * onebit_matmul_partial: zp[T,N] (fp32) = W[:, Kslice] . (h[Kslice] * x[:, Kslice])
+ *   No rounding of the sum, no g: partial sums to be all-reduced over ranks.
+ *   x is [T, K] with row pitch ldx elements (so a K-slice of a wider activation
+ *   can be passed in place); dtype of x/h as above.
+ * onebit_scale_layernorm: y = LayerNorm(g * round(z)) (+bias) from fp32 z[T,N]
+ *   (the epilogue of bitnet.py:115-120 applied after the all-reduce).
+ */
+int onebit_matmul_partial(const void *packed, int64_t ldw_bytes, const void *x, int64_t ldx,
+                          const void *h, float *zp, int64_t T, int64_t K, int64_t N, int dtype,
+                          void *stream);
+int onebit_scale_layernorm(const float *z, const void *g, const void *bias_or_null, void *y,
+                           void *u_or_null, int64_t T, int64_t N, int dtype, float ln_eps,
+                           unsigned flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONEBIT_H */

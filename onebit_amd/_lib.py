@@ -1,0 +1,78 @@
+"""ctypes binding of libonebit_hip.so (the C ABI declared in include/onebit.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+symbol is absent this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libonebit_hip.so")
+
+ONEBIT_F16, ONEBIT_F32 = 0, 1
+FLAG_SKIP_LN = 1
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); must list every symbol include/onebit.h declares
+_i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
+SYMBOLS = {
+    "onebit_abi_version": (_int, []),
+    "onebit_last_error": (ctypes.c_char_p, []),
+    "onebit_pack_signs": (_int, [_vp, _int, _vp, _i64, _i64, _vp]),
+    "onebit_unpack_signs": (_int, [_vp, _vp, _int, _i64, _i64, _vp]),
+    "onebit_linear_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _int]),
+    "onebit_linear_forward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,
+                                     _i64, _i64, _i64, _int, _f, _u, _vp]),
+    "onebit_matmul_partial": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "onebit_scale_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _u, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class OneBitLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise OneBitLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m onebit_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise OneBitLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise OneBitLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        v = lib.onebit_abi_version()
+        if v != ABI_VERSION:
+            raise OneBitLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    """Map a C-ABI return code to a Python exception (argument errors -> ValueError,
+    like the reference's view()/shape errors; HIP errors -> RuntimeError)."""
+    if rc == 0:
+        return
+    msg = load().onebit_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise RuntimeError(f"{what}: HIP error {rc}: {msg}")

@@ -1,0 +1,189 @@
+"""``BitLinearInf`` -- MI355X-native drop-in for OneBit's packed 1-bit linear layer.
+
+Mirrors the reference module ``transformers/src/transformers/models/bitnet.py:71-122``
+(class ``BitLinearInf``): same constructor signature, attribute and parameter names,
+dtypes, shapes and ``requires_grad=False`` flags, so a state dict produced by the
+reference converter (``scripts/convert_llama_to_infer_ckpt.py``) loads unchanged and
+the converter's in-place ``module.weight.data = ...`` assignments keep working (the
+kernels consume the reference's own ``int8 [N, K/8]`` layout directly; nothing is
+cached or re-laid-out).
+
+The forward pass does not unpack the weight matrix (the reference rebuilds a dense
++-1 matrix on every call, bitnet.py:98-110,114): it calls the C ABI of
+``libonebit_hip.so`` (``include/onebit.h``), hand-written HIP kernels for gfx950.
+There is no CPU fallback; CPU tensors raise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["BitLinearInf", "OneBitLinear", "int8_to_fp16", "fp16_to_int8", "pack_signs"]
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float16:
+        return _lib.ONEBIT_F16
+    if dtype == torch.float32:
+        return _lib.ONEBIT_F32
+    raise TypeError(f"OneBit HIP kernels support float16 and float32 parameters, got {dtype}")
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on {t.device}; the OneBit path runs only on a ROCm GPU "
+            "(hand-written HIP kernels, no CPU fallback)")
+
+
+def int8_to_fp16(int8_tensor: torch.Tensor, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """Dense +-1 matrix from packed signs -- ``BitLinearInf.int8_to_fp16`` (bitnet.py:98-110)."""
+    _require_gpu(int8_tensor, "int8_to_fp16")
+    if int8_tensor.dim() != 2 or int8_tensor.dtype not in (torch.int8, torch.uint8):
+        raise ValueError("expected a 2-D int8 tensor [N, K/8]")
+    p = int8_tensor.contiguous()
+    N, KB = p.shape
+    out = torch.empty((N, KB * 8), dtype=dtype, device=p.device)
+    lib = _lib.load()
+    with torch.cuda.device(p.device):
+        rc = lib.onebit_unpack_signs(p.data_ptr(), out.data_ptr(), _dtype_code(dtype), N, KB * 8,
+                                     _stream_ptr(p.device))
+    _lib.check(rc, "onebit_unpack_signs")
+    return out
+
+
+def pack_signs(weight: torch.Tensor) -> torch.Tensor:
+    """``fp16_to_int8(torch.sign(weight))`` -- the converter's per-layer step
+    (scripts/convert_llama_to_infer_ckpt.py:29-30): int8 [N, K/8], 8 signs per byte
+    LSB-first, bit 1 = negative; exact zeros (and NaN) pack as +1."""
+    _require_gpu(weight, "pack_signs")
+    if weight.dim() != 2:
+        raise ValueError("expected a 2-D weight [N, K]")
+    N, K = weight.shape
+    if K % 8 != 0:
+        # the reference's view(N, -1, 8) raises here (convert_llama_to_infer_ckpt.py:11)
+        raise ValueError(f"in_features={K} is not a multiple of 8")
+    w = weight.contiguous()
+    if w.dtype not in (torch.float16, torch.float32):
+        w = w.float()
+    out = torch.empty((N, K // 8), dtype=torch.int8, device=w.device)
+    lib = _lib.load()
+    with torch.cuda.device(w.device):
+        rc = lib.onebit_pack_signs(w.data_ptr(), _dtype_code(w.dtype), out.data_ptr(), N, K,
+                                   _stream_ptr(w.device))
+    _lib.check(rc, "onebit_pack_signs")
+    return out
+
+
+def fp16_to_int8(fp16_tensor: torch.Tensor) -> torch.Tensor:
+    """Reference name for the packer (convert_llama_to_infer_ckpt.py:7-15).  Its documented
+    domain is a tensor of +1 / -1 (0 from ``torch.sign`` maps to +1), on which this is identical."""
+    return pack_signs(fp16_tensor)
+
+
+class BitLinearInf(nn.Module):
+    """``y = LayerNorm(weight_scale * (sign_matrix @ (input_factor * x))) (+ bias)``.
+
+    Parameters (all ``requires_grad=False``, bitnet.py:78-85):
+      weight        int8  [out_features, in_features // 8]  packed signs
+      weight_scale  dtype [out_features]                    g
+      input_factor  dtype [in_features]                     h
+      bias          dtype [out_features] or None            added after the LayerNorm
+    """
+
+    def __init__(self, in_features, out_features, groups=1, bias=False, device=None, dtype=None):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.groups = groups            # accepted and ignored, as in the reference (bitnet.py:77)
+        self.weight = nn.Parameter(
+            torch.empty((out_features, in_features // 8), device=device, dtype=torch.int8),
+            requires_grad=False)
+        self.weight_scale = nn.Parameter(torch.empty(out_features, **factory_kwargs), requires_grad=False)
+        self.input_factor = nn.Parameter(torch.empty(in_features, **factory_kwargs), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features, **factory_kwargs), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+        # parameter-free LayerNorm over out_features (bitnet.py:86); kept as a submodule so that
+        # `module.layernorm.eps` / replacing it with nn.Identity() behave as in the reference.
+        self.layernorm = nn.LayerNorm(out_features, elementwise_affine=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # bitnet.py:89-96: g = h = 1, packed weight = 0 (all +1)
+        nn.init.constant_(self.weight_scale, 1.0)
+        nn.init.constant_(self.input_factor, 1.0)
+        with torch.no_grad():
+            self.weight.zero_()
+        if self.bias is not None:
+            fan_in = self.weight.shape[1]           # what _calculate_fan_in_and_fan_out sees: K // 8
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def int8_to_fp16(self, int8_tensor):
+        return int8_to_fp16(int8_tensor, self.weight_scale.dtype)
+
+    def extra_repr(self):
+        return (f"in_features={self.in_features}, out_features={self.out_features}, "
+                f"bias={self.bias is not None}")
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        K, N = self.in_features, self.out_features
+        if input.shape[-1] != K:
+            raise RuntimeError(f"BitLinearInf: expected last dim {K}, got {tuple(input.shape)}")
+        _require_gpu(input, "BitLinearInf.forward")
+        _require_gpu(self.weight, "BitLinearInf.forward (parameters)")
+        pdt = self.weight_scale.dtype
+        # bitnet.py:113 multiplies input by input_factor (type promotion), :115 then needs the
+        # product to have the dtype of the unpacked weight (= weight_scale.dtype).
+        cdt = torch.promote_types(input.dtype, self.input_factor.dtype)
+        if cdt != pdt:
+            raise RuntimeError(
+                f"BitLinearInf: input dtype {input.dtype} with parameters of dtype {pdt} "
+                f"(the reference's F.linear raises on this mix as well)")
+        code = _dtype_code(cdt)
+        if isinstance(self.layernorm, nn.Identity):
+            flags, eps = _lib.FLAG_SKIP_LN, 0.0
+        elif isinstance(self.layernorm, nn.LayerNorm) and not self.layernorm.elementwise_affine:
+            flags, eps = 0, float(self.layernorm.eps)
+        else:
+            raise RuntimeError("BitLinearInf.layernorm must be the parameter-free LayerNorm or nn.Identity")
+
+        x = input.to(cdt).reshape(-1, K)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        T = x.shape[0]
+        w = self.weight
+        if w.dim() != 2 or w.shape[0] != N or w.shape[1] != K // 8 or w.dtype not in (torch.int8, torch.uint8):
+            raise RuntimeError(f"BitLinearInf.weight must be int8 [{N}, {K // 8}], got {w.dtype} {tuple(w.shape)}")
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        h = self.input_factor.contiguous()
+        g = self.weight_scale.contiguous()
+        b = None if self.bias is None else self.bias.to(cdt).contiguous()
+        y = torch.empty((T, N), dtype=cdt, device=x.device)
+        lib = _lib.load()
+        ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        with torch.cuda.device(x.device):
+            rc = lib.onebit_linear_forward(
+                w.data_ptr(), w.stride(0), x.data_ptr(), h.data_ptr(), g.data_ptr(),
+                None if b is None else b.data_ptr(), y.data_ptr(), None,
+                None if ws is None else ws.data_ptr(), ws_bytes,
+                T, K, N, code, eps, flags, _stream_ptr(x.device))
+        _lib.check(rc, "onebit_linear_forward")
+        return y.view(*input.shape[:-1], N)
+
+
+# the name BASELINE.json uses for the layer
+OneBitLinear = BitLinearInf

@@ -1,0 +1,292 @@
+"""Host LLaMA decoder around ``BitLinearInf`` -- the caller of the hot path.
+
+Restates the inference model of the reference
+(``transformers/src/transformers/models/bitllama/modeling_bitllama.py``):
+``BitLlamaForCausalLMInf`` (:1512) -> ``LlamaModelInf`` (:1189) ->
+``LlamaDecoderLayerInf`` (:856) -> ``LlamaAttentionInf`` (:431) / ``LlamaMLPInf`` (:223),
+``LlamaRMSNorm`` (:67-81), rotary embedding (:87-113, :167-181).  Module and parameter names
+match the reference, so an inference checkpoint written by
+``scripts/convert_llama_to_infer_ckpt.py`` (``pytorch_model.bin`` keys
+``model.layers.{i}.self_attn.q_proj.{weight,weight_scale,input_factor}`` ...) loads with
+``load_state_dict`` unchanged.
+
+This file is the eager ("module") form: every 1-bit projection goes through
+``BitLinearInf.forward`` -> C ABI; the glue (RMSNorm, RoPE, attention, SiLU, residuals, lm_head)
+is plain torch in the reference's op order and rounding points.  The KV cache is preallocated
+(the reference grows it with ``torch.cat``, :536-541).  The fused whole-token decode engine lives
+in ``onebit_amd/engine.py``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .bitnet import BitLinearInf
+
+
+@dataclass
+class OneBitLlamaConfig:
+    """Defaults = LLaMA-7B, configuration_bitllama.py:117-136."""
+    vocab_size: int = 32000
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: Optional[int] = None
+    max_position_embeddings: int = 2048
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    attention_bias: bool = False
+
+    def __post_init__(self):
+        if self.num_key_value_heads is None:
+            self.num_key_value_heads = self.num_attention_heads
+        if self.hidden_size % self.num_attention_heads:
+            raise ValueError("hidden_size must be divisible by num_heads")
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @staticmethod
+    def llama_7b() -> "OneBitLlamaConfig":
+        return OneBitLlamaConfig()
+
+    @staticmethod
+    def llama_13b() -> "OneBitLlamaConfig":
+        return OneBitLlamaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40,
+                                 num_attention_heads=40)
+
+
+class LlamaRMSNorm(nn.Module):
+    """modeling_bitllama.py:67-81 (weight frozen)."""
+
+    def __init__(self, hidden_size, eps=1e-6, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states):
+        input_dtype = hidden_states.dtype
+        hidden_states = hidden_states.to(torch.float32)
+        variance = hidden_states.pow(2).mean(-1, keepdim=True)
+        hidden_states = hidden_states * torch.rsqrt(variance + self.variance_epsilon)
+        return self.weight * hidden_states.to(input_dtype)
+
+
+def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype):
+    """cos/sin caches of LlamaRotaryEmbedding (:87-113): fp32 tables cast to the model dtype."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32, device=device) / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float32, device=device)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rotate_half(x):
+    x1 = x[..., : x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+class LlamaMLPInf(nn.Module):
+    """modeling_bitllama.py:223-259."""
+
+    def __init__(self, config: OneBitLlamaConfig, dtype=None):
+        super().__init__()
+        self.gate_proj = BitLinearInf(config.hidden_size, config.intermediate_size, bias=False, dtype=dtype)
+        self.up_proj = BitLinearInf(config.hidden_size, config.intermediate_size, bias=False, dtype=dtype)
+        self.down_proj = BitLinearInf(config.intermediate_size, config.hidden_size, bias=False, dtype=dtype)
+
+    def forward(self, x):
+        return self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class LlamaAttentionInf(nn.Module):
+    """modeling_bitllama.py:431-585, eager attention, preallocated KV cache."""
+
+    def __init__(self, config: OneBitLlamaConfig, dtype=None):
+        super().__init__()
+        self.config = config
+        H, Hkv, D = config.num_attention_heads, config.num_key_value_heads, config.head_dim
+        self.num_heads, self.num_key_value_heads, self.head_dim = H, Hkv, D
+        self.hidden_size = config.hidden_size
+        self.q_proj = BitLinearInf(self.hidden_size, H * D, bias=config.attention_bias, dtype=dtype)
+        self.k_proj = BitLinearInf(self.hidden_size, Hkv * D, bias=config.attention_bias, dtype=dtype)
+        self.v_proj = BitLinearInf(self.hidden_size, Hkv * D, bias=config.attention_bias, dtype=dtype)
+        self.o_proj = BitLinearInf(H * D, self.hidden_size, bias=config.attention_bias, dtype=dtype)
+
+    def forward(self, hidden_states, cos, sin, kv: Tuple[torch.Tensor, torch.Tensor], past_len: int):
+        B, S, _ = hidden_states.shape
+        H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_dim
+        q = self.q_proj(hidden_states).view(B, S, H, D).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(B, S, Hkv, D).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(B, S, Hkv, D).transpose(1, 2)
+        c = cos[past_len:past_len + S][None, None]
+        s = sin[past_len:past_len + S][None, None]
+        q = (q * c) + (_rotate_half(q) * s)                  # apply_rotary_pos_emb, :175-181
+        k = (k * c) + (_rotate_half(k) * s)
+        kc, vc = kv
+        kc[:B, :, past_len:past_len + S] = k
+        vc[:B, :, past_len:past_len + S] = v
+        L = past_len + S
+        keys, vals = kc[:B, :, :L], vc[:B, :, :L]
+        if Hkv != H:
+            rep = H // Hkv
+            keys = keys.repeat_interleave(rep, dim=1)
+            vals = vals.repeat_interleave(rep, dim=1)
+        w = torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(D)       # :546
+        if S > 1:
+            mask = torch.full((S, L), torch.finfo(w.dtype).min, device=w.device, dtype=w.dtype)
+            mask = torch.triu(mask, diagonal=past_len + 1)
+            w = w + mask[None, None]
+        w = nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)   # :562
+        o = torch.matmul(w, vals).transpose(1, 2).contiguous().reshape(B, S, H * D)
+        return self.o_proj(o)
+
+
+class LlamaDecoderLayerInf(nn.Module):
+    """modeling_bitllama.py:856-928."""
+
+    def __init__(self, config: OneBitLlamaConfig, dtype=None):
+        super().__init__()
+        self.self_attn = LlamaAttentionInf(config, dtype)
+        self.mlp = LlamaMLPInf(config, dtype)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, dtype=dtype)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, dtype=dtype)
+
+    def forward(self, h, cos, sin, kv, past_len):
+        h = h + self.self_attn(self.input_layernorm(h), cos, sin, kv, past_len)
+        h = h + self.mlp(self.post_attention_layernorm(h))
+        return h
+
+
+class LlamaModelInf(nn.Module):
+    """modeling_bitllama.py:1189-1335."""
+
+    def __init__(self, config: OneBitLlamaConfig, dtype=None):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, dtype=dtype)
+        self.embed_tokens.weight.requires_grad_(False)
+        self.layers = nn.ModuleList([LlamaDecoderLayerInf(config, dtype) for _ in range(config.num_hidden_layers)])
+        self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, dtype=dtype)
+
+
+class KVCache:
+    """Preallocated [B, Hkv, max_len, D] key/value buffers per layer."""
+
+    def __init__(self, config: OneBitLlamaConfig, batch: int, max_len: int, device, dtype):
+        shape = (batch, config.num_key_value_heads, max_len, config.head_dim)
+        self.layers: List[Tuple[torch.Tensor, torch.Tensor]] = [
+            (torch.zeros(shape, device=device, dtype=dtype), torch.zeros(shape, device=device, dtype=dtype))
+            for _ in range(config.num_hidden_layers)]
+        self.length = 0
+        self.max_len = max_len
+
+
+class OneBitLlamaForCausalLM(nn.Module):
+    """``BitLlamaForCausalLMInf`` (modeling_bitllama.py:1512): fp16 lm_head, logits returned
+    as fp32 (:1610-1611)."""
+
+    def __init__(self, config: OneBitLlamaConfig, dtype=torch.float16):
+        super().__init__()
+        self.config = config
+        self.model = LlamaModelInf(config, dtype)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False, dtype=dtype)
+        self.lm_head.weight.requires_grad_(False)
+        self._rope = None
+
+    def _rope_tables(self, device, dtype):
+        if self._rope is None or self._rope[0].device != device or self._rope[0].dtype != dtype:
+            self._rope = rope_tables(self.config.head_dim, self.config.max_position_embeddings,
+                                     self.config.rope_theta, device, dtype)
+        return self._rope
+
+    def new_cache(self, batch: int = 1, max_len: Optional[int] = None) -> KVCache:
+        p = self.lm_head.weight
+        return KVCache(self.config, batch, max_len or self.config.max_position_embeddings, p.device, p.dtype)
+
+    @torch.no_grad()
+    def forward(self, input_ids: torch.Tensor, cache: Optional[KVCache] = None) -> torch.Tensor:
+        """input_ids [B, S] -> fp32 logits [B, S, vocab]; appends to ``cache`` when given."""
+        B, S = input_ids.shape
+        if cache is None:
+            cache = self.new_cache(B, S)
+        past = cache.length
+        if past + S > cache.max_len:
+            raise ValueError("KV cache too small")
+        h = self.model.embed_tokens(input_ids)
+        cos, sin = self._rope_tables(h.device, h.dtype)
+        for layer, kv in zip(self.model.layers, cache.layers):
+            h = layer(h, cos, sin, kv, past)
+        cache.length = past + S
+        h = self.model.norm(h)
+        return self.lm_head(h).float()
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
+        """Greedy search (generation/utils.py:2338, loop :2491-2540): argmax of the last position."""
+        B, S = input_ids.shape
+        cache = self.new_cache(B, S + max_new_tokens)
+        logits = self.forward(input_ids, cache)
+        out = [input_ids]
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(max_new_tokens):
+            out.append(nxt)
+            if len(out) - 1 == max_new_tokens:
+                break
+            logits = self.forward(nxt, cache)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+        return torch.cat(out, dim=1)
+
+
+def synthetic_state_dict(config: OneBitLlamaConfig, seed: int = 0, dtype=torch.float16, device="cpu"):
+    """Seeded synthetic OneBit checkpoint in the reference's on-disk key layout (SURVEY.md 3.4 /
+    8d): packed W = uniform random bytes, h, g = 0.1*U(0.5,1.5) with 10% sign flips, RMSNorm = 1,
+    embeddings N(0,1), lm_head N(0, 0.02).  ``device="cpu"`` is bit-reproducible (fixtures);
+    a GPU device generates the same distribution quickly for full-size benchmarks."""
+    sd = {}
+    device = torch.device(device)
+    H, I, D = config.hidden_size, config.intermediate_size, config.head_dim
+    Hq, Hkv = config.num_attention_heads * D, config.num_key_value_heads * D
+    projs = [("self_attn.q_proj", H, Hq), ("self_attn.k_proj", H, Hkv), ("self_attn.v_proj", H, Hkv),
+             ("self_attn.o_proj", Hq, H), ("mlp.gate_proj", H, I), ("mlp.up_proj", H, I),
+             ("mlp.down_proj", I, H)]
+
+    def scale(n, g):
+        v = 0.1 * (0.5 + torch.rand(n, generator=g, device=device))
+        flip = torch.where(torch.rand(n, generator=g, device=device) < 0.1, -1.0, 1.0)
+        return (v * flip).to(dtype)
+
+    for l in range(config.num_hidden_layers):
+        for p, (name, K, N) in enumerate(projs):
+            g = torch.Generator(device=device).manual_seed(seed + 1000 * l + p)
+            pre = f"model.layers.{l}.{name}."
+            sd[pre + "weight"] = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8,
+                                               device=device).view(torch.int8)
+            sd[pre + "input_factor"] = scale(K, g)
+            sd[pre + "weight_scale"] = scale(N, g)
+        sd[f"model.layers.{l}.input_layernorm.weight"] = torch.ones(H, dtype=dtype, device=device)
+        sd[f"model.layers.{l}.post_attention_layernorm.weight"] = torch.ones(H, dtype=dtype, device=device)
+    g = torch.Generator(device=device).manual_seed(seed + 999_983)
+    sd["model.embed_tokens.weight"] = torch.randn(config.vocab_size, H, generator=g, device=device).to(dtype)
+    sd["model.norm.weight"] = torch.ones(H, dtype=dtype, device=device)
+    sd["lm_head.weight"] = (0.02 * torch.randn(config.vocab_size, H, generator=g, device=device)).to(dtype)
+    return sd
+
+
+def build_synthetic_model(config: OneBitLlamaConfig, seed: int = 0, dtype=torch.float16,
+                          device="cuda") -> "OneBitLlamaForCausalLM":
+    """Random-init model of the given architecture with weights generated on `device`."""
+    with torch.device("meta"):
+        model = OneBitLlamaForCausalLM(config, dtype)
+    model = model.to_empty(device=device)
+    sd = synthetic_state_dict(config, seed, dtype, device)
+    model.load_state_dict(sd, assign=True)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.eval()

@@ -123,9 +123,8 @@ def test_forward_reset_state_constant_rows(golden_dir, coracle):
         fn = coracle.forward_f32 if c["dtype"] == "f32" else coracle.forward_f16
         y, u = fn(c["packed"], c["x"], c["h"], c["g"], None, return_pre_ln=True)
         assert np.abs(u.astype(np.float32) - c["u"].astype(np.float32)).max() <= 1e-2
-        # the reference's fp32 accumulation order makes per-row values differ in the last
-        # bits, so its LN output is O(1) noise; ours is exactly constant -> 0.
-        assert np.abs(y.astype(np.float32)).max() <= 1e-3
+        # all u equal -> (u - mean) ~ 0 -> y ~ 0 (reference: 0 in fp32, 2.9e-6 in fp16)
+        assert np.abs(y.astype(np.float32) - c["y"].astype(np.float32)).max() <= 1e-3
 
 
 def test_c_and_numpy_oracles_agree_bitwise_fp16(coracle):
