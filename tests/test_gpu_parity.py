@@ -1,8 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the oracle and the reference's goldens.
 
 Tolerance (fp16, BASELINE.json north_star: <= 1e-3 relative fp16 error): the kernels reproduce the
-reference's fp16 rounding points, so against the oracle the pre-LayerNorm values agree to <= 1 fp16
-ulp (accumulation-order flips only) and the outputs to rel-L2 <= 1e-3 / max-abs <= 2 fp16 ulps at
+reference's fp16 rounding points, so against the oracle the pre-LayerNorm values agree to <= 2 fp16
+ulps (accumulation-order flips of z, at most doubled by the *g rounding; < 2% of elements) and the outputs to rel-L2 <= 1e-3 / max-abs <= 2 fp16 ulps at
 the output scale.  Integer work (pack / unpack) is bit-exact.
 """
 import os
@@ -42,10 +42,12 @@ def _make_layer(K, N, dt, dev, packed, h, g, bias=None):
 
 def _check_f16(y, u, y_ref, u_ref, tag):
     y, u, y_ref, u_ref = (np.asarray(a, dtype=np.float32) for a in (y, u, y_ref, u_ref))
+    # z flips by one fp16 ulp when the fp32 accumulation order straddles a rounding boundary; the
+    # following fp16(z*g) can turn that into 2 ulps of u.  Anything beyond is a bug.
     ulp_u = np.maximum(np.abs(u_ref), 2.0 ** -14) * FP16_ULP
-    bad_u = np.abs(u - u_ref) > 1.001 * ulp_u
-    assert not bad_u.any(), (tag, "pre-LN differs by more than 1 fp16 ulp", int(bad_u.sum()))
-    assert (u != u_ref).mean() <= 0.02, (tag, "too many 1-ulp flips", float((u != u_ref).mean()))
+    bad_u = np.abs(u - u_ref) > 2.001 * ulp_u
+    assert not bad_u.any(), (tag, "pre-LN differs by more than 2 fp16 ulps", int(bad_u.sum()))
+    assert (u != u_ref).mean() <= 0.02, (tag, "too many ulp flips", float((u != u_ref).mean()))
     rel = np.linalg.norm(y - y_ref) / (np.linalg.norm(y_ref) + 1e-30)
     assert rel <= 1e-3, (tag, "rel-L2", rel)
     scale = max(1.0, float(np.abs(y_ref).max()))
