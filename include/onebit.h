@@ -97,6 +97,79 @@ int onebit_scale_layernorm(const float *z, const void *g, const void *bias_or_nu
                            void *u_or_null, int64_t T, int64_t N, int dtype, float ln_eps,
                            unsigned flags, void *stream);
 
+/* ---- whole-token greedy decode, batch 1 ---------------------
+ * One call enqueues every kernel of one decoded token of the reference's
+ * BitLlamaForCausalLMInf (modeling_bitllama.py:1512; decoder layer :856-928, attention
+ * :487-585, MLP :234-259, RMSNorm :67-81, greedy argmax generation/utils.py:2540):
+ * 5 launches per decoder layer + lm_head + argmax.  The token id and the position live in
+ * device memory (state->token, state->pos) and are advanced by the last kernel, so the
+ * same call sequence can be captured once in a HIP graph and replayed per token.
+ * All tensors fp16 except packed weights (int8) and the fp32/int32 scratch noted below.
+ * Requires in_features % 32 == 0 for every projection and head_dim % 8 == 0.
+ */
+typedef struct onebit_proj {
+    const void *weight;         /* int8  [N, ldw_bytes]  packed signs                     */
+    const void *input_factor;   /* fp16  [K]                                              */
+    const void *weight_scale;   /* fp16  [N]                                              */
+    int64_t N, K, ldw_bytes;
+} onebit_proj_t;
+
+typedef struct onebit_layer {
+    onebit_proj_t q, k, v, o, gate, up, down;
+    const void *input_layernorm_w;            /* fp16 [hidden] */
+    const void *post_attention_layernorm_w;   /* fp16 [hidden] */
+    void *k_cache, *v_cache;                  /* fp16 [n_kv_heads, max_len, head_dim] */
+} onebit_layer_t;
+
+typedef struct onebit_model {
+    int32_t n_layers, hidden, intermediate, n_heads, n_kv_heads, head_dim, vocab, max_len;
+    float rms_eps, ln_eps;
+    const onebit_layer_t *layers;             /* HOST array of n_layers entries */
+    const void *embed;                        /* fp16 [vocab, hidden]   */
+    const void *final_norm_w;                 /* fp16 [hidden]          */
+    const void *lm_head;                      /* fp16 [vocab, hidden]   */
+    const void *rope_cos, *rope_sin;          /* fp16 [max_pos, head_dim] (fp32 tables cast to fp16, :87-113) */
+} onebit_model_t;
+
+typedef struct onebit_decode_state {
+    int32_t *token;             /* device: in = token to process, out = greedy next token      */
+    int32_t *pos;               /* device: tokens already in the KV cache; incremented         */
+    int32_t *out_tokens;        /* device [max_out] or NULL: out_tokens[pos_before] = next     */
+    int32_t max_out;
+    void *hres0, *hres1;        /* fp16 [hidden] residual stream ping-pong                     */
+    void *u_q, *u_k, *u_v;      /* fp16 [n_heads*head_dim], [n_kv*head_dim] x2                 */
+    void *attn_out, *u_o;       /* fp16 [hidden]                                               */
+    void *u_gate, *u_up;        /* fp16 [intermediate]                                         */
+    void *u_down;               /* fp16 [hidden]                                               */
+    void *logits;               /* fp16 [vocab]                                                */
+    float *part_val;            /* fp32 [1024] argmax partials                                 */
+    int32_t *part_idx;          /* int32 [1024]                                                */
+} onebit_decode_state_t;
+
+int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t *state, void *stream);
+
+/* One fused decode GEMV launch (the building block of onebit_decode_step, exposed so that a
+ * single kernel can be measured and tested in isolation): up to 3 projections sharing the input
+ * vector x, each writing its pre-LayerNorm u = fp16(fp16(W.(h*x)) * g) to outs[i] (fp16 [N_i]).
+ * x is produced by the selected prologue:
+ *   ONEBIT_PRO_PLAIN       x = xin
+ *   ONEBIT_PRO_EMBED_RMS   r = embed[*token];                     x = RMSNorm(r) * rms_w
+ *   ONEBIT_PRO_RES_LN_RMS  r = hres_in + LayerNorm(u_prev);       x = RMSNorm(r) * rms_w
+ *   ONEBIT_PRO_SWIGLU      x = silu(LayerNorm(u_gate)) * LayerNorm(u_up)
+ * (r is also written to hres_out when given).  All vectors fp16, length K = in_features. */
+#define ONEBIT_PRO_PLAIN      0
+#define ONEBIT_PRO_EMBED_RMS  1
+#define ONEBIT_PRO_RES_LN_RMS 2
+#define ONEBIT_PRO_SWIGLU     3
+typedef struct onebit_fused_in {
+    const void *xin, *embed, *hres_in, *u_prev, *rms_w, *u_gate, *u_up;
+    const int32_t *token;
+    void *hres_out;
+    float rms_eps, ln_eps;
+} onebit_fused_in_t;
+int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
+                      const onebit_fused_in_t *in, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

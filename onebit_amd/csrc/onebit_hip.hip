@@ -8,6 +8,7 @@
 #include "../../include/onebit.h"
 #include "ob_linear.h"
 #include "ob_pack.h"
+#include "ob_decode.h"
 
 static thread_local char g_err[256] = "";
 
@@ -242,4 +243,182 @@ extern "C" int onebit_scale_layernorm(const float *z, const void *g, const void 
                            (const float *)nullptr, (const float *)g, (const float *)bias, (float *)y,
                            (float *)u_or_null, (int)N, ln_eps, skip);
     return ob_launch_status("scale_layernorm");
+}
+
+// --------------------------------------------------------------- decode step --
+
+static int ob_cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *name)
+{
+    if (!s.weight || !s.input_factor || !s.weight_scale || !u)
+        return ob_fail(ONEBIT_E_ARG, "decode_step: null pointer in projection %s", name);
+    if (s.K % 32 != 0 || s.ldw_bytes % 4 != 0 || s.ldw_bytes < s.K / 8 || s.N <= 0)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step: projection %s needs K %% 32 == 0 and 4-byte aligned rows", name);
+    if (s.K > 16384) return ob_fail(ONEBIT_E_SHAPE, "decode_step: projection %s: K > 16384 unsupported", name);
+    d.w = (const uint32_t *)s.weight;
+    d.h = (const _Float16 *)s.input_factor;
+    d.g = (const _Float16 *)s.weight_scale;
+    d.u = (_Float16 *)u;
+    d.N = (int)s.N; d.K = (int)s.K; d.ldw = (int)(s.ldw_bytes / 4);
+    return 0;
+}
+
+template <int PT, int MT>
+static void ob_launch_dec_gemv_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<PT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<PT, MT>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+}
+
+static int ob_launch_dec_gemv(const ObGemvArgs &a, hipStream_t s)
+{
+    int ntiles = 0;
+    for (int p = 0; p < a.nproj; ++p) ntiles += (a.p[p].N + 15) / 16;
+    const int Kpad = (a.K + 511) & ~511;
+    const int nchunks = Kpad / 512;
+    const int pt_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;
+    const int PT = pt_need <= 1 ? 1 : (pt_need <= 2 ? 2 : 4);
+    const int mt_max = PT == 1 ? 8 : (PT == 2 ? 4 : 2);
+    int G = ob_cu_count();
+    if (ntiles < G) G = ntiles;
+    if ((ntiles + G - 1) / G > mt_max) G = (ntiles + mt_max - 1) / mt_max;
+    const int mt_need = (ntiles + G - 1) / G;
+    const int MT = mt_need <= 1 ? 1 : (mt_need <= 2 ? 2 : (mt_need <= 4 ? 4 : 8));
+    const size_t lds = (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 128 * 4;
+    if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: LDS need %zu > 160 KiB", lds);
+#define OB_CASE(P, M) if (PT == P && MT == M) { ob_launch_dec_gemv_t<P, M>(a, G, lds, s); return ob_launch_status("decode_step(gemv)"); }
+    OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 4) OB_CASE(1, 8)
+    OB_CASE(2, 1) OB_CASE(2, 2) OB_CASE(2, 4)
+    OB_CASE(4, 1) OB_CASE(4, 2)
+#undef OB_CASE
+    return ob_fail(ONEBIT_E_SHAPE, "decode_step: no kernel instance for PT=%d MT=%d", PT, MT);
+}
+
+extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
+                                 const onebit_fused_in_t *in, void *stream)
+{
+    if (!projs || !outs || !in || nproj < 1 || nproj > 3) return ob_fail(ONEBIT_E_ARG, "fused_gemv: bad arguments");
+    ObGemvArgs a = {};
+    a.nproj = nproj; a.K = (int)projs[0].K; a.prologue = prologue;
+    int rc;
+    for (int p = 0; p < nproj; ++p) {
+        if (projs[p].K != projs[0].K) return ob_fail(ONEBIT_E_SHAPE, "fused_gemv: projections must share in_features");
+        if ((rc = ob_fill_proj(a.p[p], projs[p], outs[p], "fused"))) return rc;
+    }
+    a.xin = (const _Float16 *)in->xin; a.embed = (const _Float16 *)in->embed; a.token = in->token;
+    a.hres_in = (const _Float16 *)in->hres_in; a.u_prev = (const _Float16 *)in->u_prev;
+    a.hres_out = (_Float16 *)in->hres_out; a.rms_w = (const _Float16 *)in->rms_w;
+    a.u_gate = (const _Float16 *)in->u_gate; a.u_up = (const _Float16 *)in->u_up;
+    a.rms_eps = in->rms_eps; a.ln_eps = in->ln_eps;
+    bool ok = false;
+    switch (prologue) {
+    case OB_P_PLAIN: ok = a.xin != nullptr; break;
+    case OB_P_EMBED_RMS: ok = a.embed && a.token && a.rms_w; break;
+    case OB_P_RES_LN_RMS: ok = a.hres_in && a.u_prev && a.rms_w; break;
+    case OB_P_SWIGLU: ok = a.u_gate && a.u_up; break;
+    default: return ob_fail(ONEBIT_E_FLAG, "fused_gemv: unknown prologue %d", prologue);
+    }
+    if (!ok) return ob_fail(ONEBIT_E_ARG, "fused_gemv: null input for prologue %d", prologue);
+    return ob_launch_dec_gemv(a, (hipStream_t)stream);
+}
+
+extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_state_t *st, void *stream)
+{
+    if (!m || !st || !m->layers) return ob_fail(ONEBIT_E_ARG, "decode_step: null model/state");
+    if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
+        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 256 || m->hidden % 8 != 0 ||
+        m->intermediate % 8 != 0 || m->max_len <= 0 || m->vocab <= 0)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step: unsupported model dimensions");
+    if (!st->token || !st->pos || !st->hres0 || !st->hres1 || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
+        !st->u_o || !st->u_gate || !st->u_up || !st->u_down || !st->logits || !st->part_val || !st->part_idx ||
+        !m->embed || !m->final_norm_w || !m->lm_head || !m->rope_cos || !m->rope_sin)
+        return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = m->hidden, I = m->intermediate, D = m->head_dim;
+    _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
+    int rc;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const onebit_layer_t &L = m->layers[l];
+        if (!L.k_cache || !L.v_cache || !L.input_layernorm_w || !L.post_attention_layernorm_w)
+            return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer in layer %d", l);
+        // K1: residual (+LN of previous down) -> RMSNorm -> q, k, v
+        ObGemvArgs a = {};
+        a.nproj = 3; a.K = H;
+        if ((rc = ob_fill_proj(a.p[0], L.q, st->u_q, "q_proj"))) return rc;
+        if ((rc = ob_fill_proj(a.p[1], L.k, st->u_k, "k_proj"))) return rc;
+        if ((rc = ob_fill_proj(a.p[2], L.v, st->u_v, "v_proj"))) return rc;
+        if (L.q.K != H || L.k.K != H || L.v.K != H || L.q.N != (int64_t)m->n_heads * D || L.k.N != (int64_t)m->n_kv_heads * D ||
+            L.v.N != L.k.N || L.o.K != L.q.N || L.o.N != H || L.gate.K != H || L.up.K != H || L.gate.N != I ||
+            L.up.N != I || L.down.K != I || L.down.N != H)
+            return ob_fail(ONEBIT_E_SHAPE, "decode_step: layer %d projection shapes do not match the model", l);
+        a.prologue = l == 0 ? OB_P_EMBED_RMS : OB_P_RES_LN_RMS;
+        a.embed = (const _Float16 *)m->embed; a.token = st->token;
+        a.hres_in = hA; a.u_prev = (const _Float16 *)st->u_down; a.hres_out = hB;
+        a.rms_w = (const _Float16 *)L.input_layernorm_w;
+        a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
+        if ((rc = ob_launch_dec_gemv(a, s))) return rc;
+        // K2: attention
+        ObAttnArgs at = {};
+        at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
+        at.cos = (const _Float16 *)m->rope_cos; at.sin = (const _Float16 *)m->rope_sin;
+        at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
+        at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
+        at.ln_eps = m->ln_eps;
+        const size_t attn_lds = 512 + (size_t)10 * D + (size_t)4 * m->max_len + (size_t)16 * D;
+        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
+        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(256), attn_lds, s, at);
+        if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
+        // K3: o_proj
+        ObGemvArgs o = {};
+        o.nproj = 1; o.K = (int)L.o.K; o.prologue = OB_P_PLAIN; o.xin = (const _Float16 *)st->attn_out;
+        if ((rc = ob_fill_proj(o.p[0], L.o, st->u_o, "o_proj"))) return rc;
+        o.rms_eps = m->rms_eps; o.ln_eps = m->ln_eps;
+        if ((rc = ob_launch_dec_gemv(o, s))) return rc;
+        // K4: residual + LN(u_o) -> RMSNorm -> gate, up
+        ObGemvArgs gu = {};
+        gu.nproj = 2; gu.K = H; gu.prologue = OB_P_RES_LN_RMS;
+        if ((rc = ob_fill_proj(gu.p[0], L.gate, st->u_gate, "gate_proj"))) return rc;
+        if ((rc = ob_fill_proj(gu.p[1], L.up, st->u_up, "up_proj"))) return rc;
+        gu.hres_in = hB; gu.u_prev = (const _Float16 *)st->u_o; gu.hres_out = hA;
+        gu.rms_w = (const _Float16 *)L.post_attention_layernorm_w;
+        gu.rms_eps = m->rms_eps; gu.ln_eps = m->ln_eps;
+        if ((rc = ob_launch_dec_gemv(gu, s))) return rc;
+        // K5: silu(LN(gate)) * LN(up) -> down
+        ObGemvArgs dn = {};
+        dn.nproj = 1; dn.K = I; dn.prologue = OB_P_SWIGLU;
+        if ((rc = ob_fill_proj(dn.p[0], L.down, st->u_down, "down_proj"))) return rc;
+        dn.u_gate = (const _Float16 *)st->u_gate; dn.u_up = (const _Float16 *)st->u_up;
+        dn.rms_eps = m->rms_eps; dn.ln_eps = m->ln_eps;
+        if ((rc = ob_launch_dec_gemv(dn, s))) return rc;
+    }
+    // final norm + lm_head + argmax
+    ObHeadArgs hd = {};
+    hd.hres_in = hA; hd.u_prev = (const _Float16 *)st->u_down; hd.rms_w = (const _Float16 *)m->final_norm_w;
+    hd.lm_w = (const _Float16 *)m->lm_head; hd.logits = (_Float16 *)st->logits;
+    hd.part_val = st->part_val; hd.part_idx = st->part_idx; hd.hres_out = hB;
+    hd.K = H; hd.V = m->vocab; hd.rms_eps = m->rms_eps; hd.ln_eps = m->ln_eps;
+    int G = ob_cu_count();
+    if (G > 1024) G = 1024;
+    const size_t head_lds = (size_t)H * 2 + 64 * 4 + 64 * 4;
+    hipLaunchKernelGGL(ob_dec_lmhead_kernel, dim3(G), dim3(OB_DEC_THREADS), head_lds, s, hd);
+    if ((rc = ob_launch_status("decode_step(lm_head)"))) return rc;
+    hipLaunchKernelGGL(ob_dec_argmax_kernel, dim3(1), dim3(256), 0, s, (const float *)st->part_val,
+                       (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out);
+    return ob_launch_status("decode_step(argmax)");
 }

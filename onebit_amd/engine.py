@@ -1,0 +1,206 @@
+"""Fused whole-token greedy decode (batch 1) -- SURVEY.md section 8(f) rank 1.
+
+``DecodeEngine`` drives ``onebit_decode_step`` (include/onebit.h): 5 HIP launches per decoder
+layer + lm_head + argmax, every 1-bit projection read once in the reference's packed layout,
+LayerNorm / RMSNorm / RoPE / SiLU / residuals fused into the consumers' prologues, token id and
+position kept on the device.  One decode step is captured into a HIP graph (via
+``torch.cuda.CUDAGraph``) and replayed per token -- 160+ launches per token would otherwise be
+host-bound (the reference issues ~10 ATen launches per BitLinearInf call).
+
+Prefill of the prompt (S > 1) runs through the module path (``OneBitLlamaForCausalLM.forward``)
+into the same preallocated KV cache.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List
+
+import torch
+
+from . import _lib
+from .bitnet import BitLinearInf
+from .llama import KVCache, OneBitLlamaForCausalLM
+
+_vp, _i64, _i32, _f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float
+
+
+class _Proj(ctypes.Structure):
+    _fields_ = [("weight", _vp), ("input_factor", _vp), ("weight_scale", _vp),
+                ("N", _i64), ("K", _i64), ("ldw_bytes", _i64)]
+
+
+class _Layer(ctypes.Structure):
+    _fields_ = [("q", _Proj), ("k", _Proj), ("v", _Proj), ("o", _Proj), ("gate", _Proj), ("up", _Proj),
+                ("down", _Proj), ("input_layernorm_w", _vp), ("post_attention_layernorm_w", _vp),
+                ("k_cache", _vp), ("v_cache", _vp)]
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [("n_layers", _i32), ("hidden", _i32), ("intermediate", _i32), ("n_heads", _i32),
+                ("n_kv_heads", _i32), ("head_dim", _i32), ("vocab", _i32), ("max_len", _i32),
+                ("rms_eps", _f), ("ln_eps", _f), ("layers", ctypes.POINTER(_Layer)),
+                ("embed", _vp), ("final_norm_w", _vp), ("lm_head", _vp), ("rope_cos", _vp), ("rope_sin", _vp)]
+
+
+class _State(ctypes.Structure):
+    _fields_ = [("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
+                ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
+                ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
+                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp)]
+
+
+class _FusedIn(ctypes.Structure):
+    _fields_ = [("xin", _vp), ("embed", _vp), ("hres_in", _vp), ("u_prev", _vp), ("rms_w", _vp),
+                ("u_gate", _vp), ("u_up", _vp), ("token", _vp), ("hres_out", _vp),
+                ("rms_eps", _f), ("ln_eps", _f)]
+
+
+PRO_PLAIN, PRO_EMBED_RMS, PRO_RES_LN_RMS, PRO_SWIGLU = 0, 1, 2, 3
+
+
+def fused_gemv(mods, outs, prologue, rms_eps=1e-6, ln_eps=1e-5, **inputs):
+    """One ``onebit_fused_gemv`` launch on the current stream: projections ``mods`` (BitLinearInf
+    sharing in_features) write their pre-LayerNorm outputs to ``outs`` (fp16 [N_i] tensors);
+    ``inputs`` are the prologue tensors named as in ``onebit_fused_in_t``."""
+    lib = _lib.load()
+    n = len(mods)
+    projs = (_Proj * n)(*[_proj(m) for m in mods])
+    optr = (_vp * n)(*[o.data_ptr() for o in outs])
+    ptr = lambda k: inputs[k].data_ptr() if inputs.get(k) is not None else None
+    fin = _FusedIn(ptr("xin"), ptr("embed"), ptr("hres_in"), ptr("u_prev"), ptr("rms_w"), ptr("u_gate"),
+                   ptr("u_up"), ptr("token"), ptr("hres_out"), rms_eps, ln_eps)
+    dev = outs[0].device
+    with torch.cuda.device(dev):
+        rc = lib.onebit_fused_gemv(ctypes.cast(projs, _vp), ctypes.cast(optr, _vp), n, prologue,
+                                   ctypes.cast(ctypes.pointer(fin), _vp),
+                                   torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "onebit_fused_gemv")
+
+
+def _proj(m: BitLinearInf) -> _Proj:
+    if m.bias is not None:
+        raise ValueError("DecodeEngine: projections with bias are not supported (LLaMA uses bias=False)")
+    if m.weight_scale.dtype != torch.float16 or m.input_factor.dtype != torch.float16:
+        raise ValueError("DecodeEngine needs an fp16 model (model.half())")
+    if m.in_features % 32 != 0:
+        raise ValueError(f"DecodeEngine: in_features={m.in_features} is not a multiple of 32; use the module path")
+    w = m.weight
+    if w.stride(1) != 1 or not m.weight_scale.is_contiguous() or not m.input_factor.is_contiguous():
+        raise ValueError("DecodeEngine: parameters must be contiguous")
+    return _Proj(w.data_ptr(), m.input_factor.data_ptr(), m.weight_scale.data_ptr(),
+                 m.out_features, m.in_features, w.stride(0))
+
+
+class DecodeEngine:
+    def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True):
+        cfg = model.config
+        p = model.lm_head.weight
+        if not p.is_cuda:
+            raise RuntimeError("DecodeEngine needs the model on a ROCm GPU (no CPU fallback)")
+        if p.dtype != torch.float16:
+            raise ValueError("DecodeEngine needs an fp16 model")
+        self.model, self.cfg, self.dev = model, cfg, p.device
+        self.lib = _lib.load()
+        if not hasattr(self.lib, "onebit_decode_step"):
+            raise _lib.OneBitLibraryError("libonebit_hip.so lacks onebit_decode_step")
+        self.max_len = int(max_len)
+        if self.max_len > cfg.max_position_embeddings:
+            raise ValueError("max_len exceeds max_position_embeddings")
+        dev, f16 = self.dev, torch.float16
+        H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        self.cache = KVCache(cfg, 1, self.max_len, dev, f16)
+        cos, sin = model._rope_tables(dev, f16)
+        self._keep = [cos.contiguous(), sin.contiguous()]
+        layers = (_Layer * cfg.num_hidden_layers)()
+        for i, (layer, (kc, vc)) in enumerate(zip(model.model.layers, self.cache.layers)):
+            a, mlp = layer.self_attn, layer.mlp
+            layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
+                               _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
+                               layer.input_layernorm.weight.data_ptr(),
+                               layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
+            for w in (layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
+                if w.dtype != f16:
+                    raise ValueError("DecodeEngine needs fp16 RMSNorm weights")
+        self._layers = layers
+        self._model = _Model(cfg.num_hidden_layers, H, I, cfg.num_attention_heads, cfg.num_key_value_heads, D,
+                             cfg.vocab_size, self.max_len, cfg.rms_norm_eps, 1e-5, layers,
+                             model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
+                             model.lm_head.weight.data_ptr(), self._keep[0].data_ptr(), self._keep[1].data_ptr())
+        z = lambda n, dt=f16: torch.zeros(n, dtype=dt, device=dev)
+        self.token = z(1, torch.int32)
+        self.pos = z(1, torch.int32)
+        self.out_tokens = z(self.max_len, torch.int32)
+        Hq, Hkv = cfg.num_attention_heads * D, cfg.num_key_value_heads * D
+        self.buf = dict(hres0=z(H), hres1=z(H), u_q=z(Hq), u_k=z(Hkv), u_v=z(Hkv), attn_out=z(Hq), u_o=z(H),
+                        u_gate=z(I), u_up=z(I), u_down=z(H), logits=z(cfg.vocab_size),
+                        part_val=z(1024, torch.float32), part_idx=z(1024, torch.int32))
+        b = self.buf
+        self._state = _State(self.token.data_ptr(), self.pos.data_ptr(), self.out_tokens.data_ptr(), self.max_len,
+                             b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
+                             b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
+                             b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr())
+        self.lib.onebit_decode_step.restype = ctypes.c_int
+        self.lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), _vp]
+        self.graph = None
+        self._prompt_len = 0
+        self._launch()                      # warm-up: validates arguments, sets function attributes
+        torch.cuda.synchronize(dev)
+        if use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch()
+            self.graph = g
+        self.pos.zero_()
+        self.token.zero_()
+
+    def _launch(self):
+        with torch.cuda.device(self.dev):
+            rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(self._state),
+                                             torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "onebit_decode_step")
+
+    @torch.no_grad()
+    def prefill(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """Run the prompt through the module path into the shared KV cache; returns the fp32 logits
+        and arms the engine with the first greedy token."""
+        if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise ValueError("DecodeEngine is batch 1: input_ids must be [1, S]")
+        S = input_ids.shape[1]
+        if S + 1 > self.max_len:
+            raise ValueError("prompt longer than max_len")
+        self.cache.length = 0
+        logits = self.model(input_ids.to(self.dev), self.cache)
+        self.token.copy_(logits[0, -1].argmax().to(torch.int32).reshape(1))
+        self.pos.fill_(S)
+        self._prompt_len = S
+        self.first_token = int(self.token.item())
+        return logits
+
+    def set_state(self, token: int, pos: int):
+        self.token.fill_(int(token))
+        self.pos.fill_(int(pos))
+
+    def step(self):
+        """Decode one token (asynchronous): consumes the device-side token, appends to the KV cache,
+        leaves the next greedy token on the device."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+
+    def logits(self) -> torch.Tensor:
+        """fp32 logits of the last step (the reference returns logits.float())."""
+        return self.buf["logits"].float()
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
+        self.prefill(input_ids)
+        n = min(max_new_tokens - 1, self.max_len - self._prompt_len - 1)
+        for _ in range(max(n, 0)):
+            self.step()
+        torch.cuda.synchronize(self.dev)
+        new: List[int] = [self.first_token]
+        if n > 0:
+            new += self.out_tokens[self._prompt_len:self._prompt_len + n].tolist()
+        return torch.cat([input_ids.to(self.dev), torch.tensor([new], device=self.dev, dtype=input_ids.dtype)], dim=1)
