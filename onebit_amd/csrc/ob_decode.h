@@ -52,15 +52,17 @@ struct ObGemvArgs {
     const _Float16 *rms_w;         // RMSNorm weight [K]
     const _Float16 *u_gate, *u_up; // SWIGLU: pre-LN gate / up [K]
     float rms_eps, ln_eps;
+    int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
 };
 
+// Block-wide sums of NV values through LDS.  `red` must be a slot (16*NV floats) not used by any
+// other reduction still in flight, so a single barrier suffices.
 template <int NV>
 __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
 {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = ob_wave_sum(v[i]);
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) red[i * 16 + wave] = v[i];
@@ -94,153 +96,6 @@ __device__ __forceinline__ float ob_silu_h(float x)   // fp16 silu: fp32 math, o
     return ob_round_h(x / (1.0f + __expf(-x)));
 }
 
-// ---------------------------------------------------------------------------------------------
-// Prologue: builds x[K] (fp16 values held as float in xs[][]), then a_p = fp16(x * h_p) in LDS.
-// lds_a layout: [nproj][Kpad] halves, Kpad = K rounded up to 512 (zero padded).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ob_dec_prologue(const ObGemvArgs &A, _Float16 *lds_a, float *red, int Kpad)
-{
-    const int tid = threadIdx.x;
-    const int K = A.K;
-    float xs[OB_DEC_MAXV][8];
-    if (A.prologue == OB_P_PLAIN) {
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-                const ob_half8 t = *reinterpret_cast<const ob_half8 *>(A.xin + base);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xs[v][i] = (float)t[i];
-            }
-        }
-    } else if (A.prologue == OB_P_SWIGLU) {
-        float gs[OB_DEC_MAXV][8], us[OB_DEC_MAXV][8];
-        const float cg = (float)A.u_gate[0], cu = (float)A.u_up[0];
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-                const ob_half8 tg = *reinterpret_cast<const ob_half8 *>(A.u_gate + base);
-                const ob_half8 tu = *reinterpret_cast<const ob_half8 *>(A.u_up + base);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    gs[v][i] = (float)tg[i];
-                    us[v][i] = (float)tu[i];
-                    const float dg = gs[v][i] - cg, du = us[v][i] - cu;
-                    s[0] += dg; s[1] += dg * dg; s[2] += du; s[3] += du * du;
-                }
-            }
-        }
-        ob_block_sum_n<4>(s, red);
-        float mg, rg, mu, ru;
-        ob_ln_stats(s[0], s[1], cg, K, A.ln_eps, mg, rg);
-        ob_ln_stats(s[2], s[3], cu, K, A.ln_eps, mu, ru);
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float gate = ob_ln_apply(gs[v][i], mg, rg);
-                    const float up = ob_ln_apply(us[v][i], mu, ru);
-                    xs[v][i] = ob_round_h(ob_silu_h(gate) * up);     // act_fn(gate) * up, modeling_bitllama.py:257
-                }
-            }
-        }
-    } else {
-        // residual stream: embedding row, or h_in + LayerNorm(u_prev); then RMSNorm
-        float hv[OB_DEC_MAXV][8];
-        if (A.prologue == OB_P_EMBED_RMS) {
-            const _Float16 *row = A.embed + (int64_t)(*A.token) * K;
-#pragma unroll
-            for (int v = 0; v < OB_DEC_MAXV; ++v) {
-                const int base = (v * OB_DEC_THREADS + tid) * 8;
-                if (base < K) {
-                    const ob_half8 t = *reinterpret_cast<const ob_half8 *>(row + base);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) hv[v][i] = (float)t[i];
-                }
-            }
-        } else {
-            float uv[OB_DEC_MAXV][8];
-            const float c = (float)A.u_prev[0];
-            float s[2] = {0.f, 0.f};
-#pragma unroll
-            for (int v = 0; v < OB_DEC_MAXV; ++v) {
-                const int base = (v * OB_DEC_THREADS + tid) * 8;
-                if (base < K) {
-                    const ob_half8 tu = *reinterpret_cast<const ob_half8 *>(A.u_prev + base);
-                    const ob_half8 th = *reinterpret_cast<const ob_half8 *>(A.hres_in + base);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        uv[v][i] = (float)tu[i];
-                        hv[v][i] = (float)th[i];
-                        const float d = uv[v][i] - c;
-                        s[0] += d; s[1] += d * d;
-                    }
-                }
-            }
-            ob_block_sum_n<2>(s, red);
-            float mean, rstd;
-            ob_ln_stats(s[0], s[1], c, K, A.ln_eps, mean, rstd);
-#pragma unroll
-            for (int v = 0; v < OB_DEC_MAXV; ++v) {
-                const int base = (v * OB_DEC_THREADS + tid) * 8;
-                if (base < K) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)       // residual + hidden_states, modeling_bitllama.py:912,918
-                        hv[v][i] = ob_round_h(hv[v][i] + ob_ln_apply(uv[v][i], mean, rstd));
-                }
-            }
-        }
-        // RMSNorm (modeling_bitllama.py:76-81): fp32 variance, x * rsqrt -> fp16, * weight -> fp16
-        float ss[1] = {0.f};
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ss[0] += hv[v][i] * hv[v][i];
-            }
-        }
-        ob_block_sum_n<1>(ss, red);
-        const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-                const ob_half8 wv = *reinterpret_cast<const ob_half8 *>(A.rms_w + base);
-                ob_half8 ho;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    ho[i] = (_Float16)hv[v][i];
-                    xs[v][i] = ob_round_h((float)wv[i] * ob_round_h(hv[v][i] * rs));
-                }
-                if (blockIdx.x == 0 && A.hres_out)
-                    *reinterpret_cast<ob_half8 *>(A.hres_out + base) = ho;
-            }
-        }
-    }
-    // a_p = fp16(x * h_p)  (bitnet.py:113), zero padding up to Kpad
-    for (int p = 0; p < A.nproj; ++p) {
-        _Float16 *dst = lds_a + (size_t)p * Kpad;
-#pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
-            const int base = (v * OB_DEC_THREADS + tid) * 8;
-            if (base < K) {
-                const ob_half8 hv8 = *reinterpret_cast<const ob_half8 *>(A.p[p].h + base);
-                ob_half8 o;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (_Float16)(xs[v][i] * (float)hv8[i]);
-                *reinterpret_cast<ob_half8 *>(dst + base) = o;
-            } else if (base < Kpad) {
-                *reinterpret_cast<ob_half8 *>(dst + base) = (ob_half8)(_Float16)0;
-            }
-        }
-    }
-}
-
 // 16 MFMAs for one 512-weight chunk of a 16-row tile.  w4: this lane's 4 packed words (row = lane&15,
 // k = 128*(lane>>4) + 32*q + bit).  a: LDS activations of the chunk.  Every column of the B
 // operand carries the same token (T = 1), so no masking is needed: all 16 result columns agree.
@@ -265,70 +120,240 @@ __device__ __forceinline__ void ob_dec_chunk(const ob_u32x4 w4, const _Float16 *
     }
 }
 
-__device__ __forceinline__ ob_u32x4 ob_dec_load_w(const ObProj &P, int row0, int chunk, int lane)
+// One lane's 4 packed words of (row0 + lane&15, chunk); branch-free (indices are clamped into the
+// row and out-of-range words zeroed afterwards) so that the load can be issued ahead of everything.
+// ALIGNED: K % 128 == 0 and 16-byte aligned rows: the 4 words are all inside or all outside the row
+// and one dwordx4 does it (non-temporal: each word is read exactly once per token).
+template <bool ALIGNED>
+__device__ __forceinline__ ob_u32x4 ob_dec_load_w(const uint32_t *w, int N, int K, int ldw, int row0, int chunk, int lane)
 {
     const int r = lane & 15, gq = lane >> 4;
-    const int row = min(row0 + r, P.N - 1);
+    const int row = min(row0 + r, N - 1);
     const int word = chunk * 16 + gq * 4;
-    const int nwords = P.K >> 5;
-    const uint32_t *src = P.w + (int64_t)row * P.ldw + word;
-    ob_u32x4 w4 = {0u, 0u, 0u, 0u};
-    if (word + 4 <= nwords && (P.ldw & 3) == 0) {
-        w4 = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(src));
+    const int nwords = K >> 5;
+    const uint32_t *rowp = w + (int64_t)row * ldw;
+    ob_u32x4 w4;
+    if (ALIGNED) {
+        const int wc = min(word, nwords - 4);
+        w4 = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(rowp + wc));
+        if (word >= nwords) w4 = (ob_u32x4){0u, 0u, 0u, 0u};
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (word + q < nwords) w4[q] = src[q];
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = rowp[min(word + q, nwords - 1)];
+            w4[q] = (word + q < nwords) ? v : 0u;
+        }
     }
     return w4;
 }
 
-// dynamic LDS: [nproj * Kpad halves][MT * 8 waves * 16 rows floats][128 floats]
-// PT = max 512-weight chunks per wave per tile (ceil(K/4096)), MT = max tiles per workgroup; both
-// compile-time so that the in-flight weight registers and the accumulators are statically indexed.
-template <int PT, int MT>
+// dynamic LDS: [nproj * Kpad halves][MT * 8 waves * 16 rows floats][4 reduction slots of 64 floats]
+// KV = ceil(K / 4096): 8-half vectors per thread in the prologue AND 512-weight chunks per wave per
+// tile; MT = max tiles per workgroup; PRO = prologue.  All compile-time so that the in-flight
+// registers are statically indexed and the load phase is straight-line code: every global load of
+// the kernel (weights, prologue vectors, epilogue scales) is issued before the first use of any of
+// them (loads return in order, so one early use would serialise the rest) -- the kernel pays one
+// memory round trip, not one per stage.
+template <int KV, int MT, bool ALIGNED, int PRO>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
+    // the three projection descriptors live in SGPRs; selection by tile index is scalar arithmetic,
+    // never an indexed read of the kernel-argument segment (that costs a dependent memory round trip)
+    const ObProj P0 = A.p[0], P1 = A.p[1], P2 = A.p[2];
+#define OB_SEL(p, f) ((p) == 0 ? P0.f : ((p) == 1 ? P1.f : P2.f))
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef OB_PROFILE_ABLATE
+    if (A.ablate == 4) return;              // launch floor
+#endif
     const int K = A.K;
     const int Kpad = (K + 511) & ~511;
+    const int nproj = A.nproj;
     _Float16 *lds_a = reinterpret_cast<_Float16 *>(smem);
-    float *lds_red = reinterpret_cast<float *>(smem + (size_t)A.nproj * Kpad * 2);
+    float *lds_red = reinterpret_cast<float *>(smem + (size_t)nproj * Kpad * 2);
     float *red = lds_red + MT * OB_DEC_WAVES * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gq = lane >> 4;
     const int G = gridDim.x;
 
     // tiles are numbered projection-major; this workgroup owns tiles b, b + G, b + 2G, ...
     int tile_base[4];
     tile_base[0] = 0;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) tile_base[p + 1] = tile_base[p] + (p < A.nproj ? (A.p[p].N + 15) >> 4 : 0);
+    tile_base[1] = (P0.N + 15) >> 4;
+    tile_base[2] = tile_base[1] + (nproj > 1 ? (P1.N + 15) >> 4 : 0);
+    tile_base[3] = tile_base[2] + (nproj > 2 ? (P2.N + 15) >> 4 : 0);
     const int ntiles = tile_base[3];
     const int nchunks = Kpad >> 9;
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const int my_tiles = (ntiles - 1 - (int)blockIdx.x) / G + 1;               // >= 1 (G <= ntiles)
     const int per_tile = (nchunks - wave + OB_DEC_WAVES - 1) / OB_DEC_WAVES;   // this wave's chunks per tile
 
-    // 1. issue every weight load of this wave: items (tile j, chunk wave + 8*ci)
-    ob_u32x4 wreg[MT][PT];
+    // ---- 1. issue every global load (no use of any loaded value in this section) ----------------
+    // Loads return in order, so the vectors the prologue needs go first and the weight stream last:
+    // the prologue then waits only for its own few KB (vmcnt = number of weight loads still in
+    // flight) and runs underneath the HBM stream.
+    // 1a. prologue vectors (raw halves; indices clamped, masked later)
+    bool valid[KV];
+    int vbase[KV];
+    ob_half8 v0[KV], v1[KV], v2[KV], hp[3][KV];
+    _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+        const int base = (v * OB_DEC_THREADS + tid) * 8;
+        valid[v] = base < K;
+        vbase[v] = valid[v] ? base : 0;
+        if (PRO == OB_P_PLAIN) {
+            v0[v] = *reinterpret_cast<const ob_half8 *>(A.xin + vbase[v]);
+        } else if (PRO == OB_P_SWIGLU) {
+            v0[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + vbase[v]);
+            v1[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + vbase[v]);
+        } else {
+            if (PRO == OB_P_RES_LN_RMS) {
+                v0[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + vbase[v]);
+                v1[v] = *reinterpret_cast<const ob_half8 *>(A.hres_in + vbase[v]);
+            }
+            v2[v] = *reinterpret_cast<const ob_half8 *>(A.rms_w + vbase[v]);
+        }
+        hp[0][v] = *reinterpret_cast<const ob_half8 *>(P0.h + vbase[v]);
+        hp[1][v] = *reinterpret_cast<const ob_half8 *>((nproj > 1 ? P1.h : P0.h) + vbase[v]);
+        hp[2][v] = *reinterpret_cast<const ob_half8 *>((nproj > 2 ? P2.h : P0.h) + vbase[v]);
+    }
+    if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
+    if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
+    // 1b. embedding row: the one dependent load (token id first), once per token
+    if (PRO == OB_P_EMBED_RMS) {
+        const _Float16 *row = A.embed + (int64_t)(*A.token) * K;
+#pragma unroll
+        for (int v = 0; v < KV; ++v) v1[v] = *reinterpret_cast<const ob_half8 *>(row + vbase[v]);
+    }
+    // 1c. epilogue scale g of the output row this thread will finalise (clamped, raw)
+    const bool fin = tid < my_tiles * 16;
+    const int t_out = blockIdx.x + (fin ? (tid >> 4) : 0) * G;
+    const int p_out = t_out >= tile_base[2] ? 2 : (t_out >= tile_base[1] ? 1 : 0);
+    const int n_raw = ((t_out - tile_base[p_out]) << 4) + (tid & 15);
+    const int N_out = OB_SEL(p_out, N);
+    const int n_out = min(n_raw, N_out - 1);
+    const _Float16 g_h = OB_SEL(p_out, g)[n_out];
+    _Float16 *u_out = OB_SEL(p_out, u);
+    __builtin_amdgcn_sched_barrier(0);
+    // 1d. packed weights: items (tile j, chunk wave + 8*ci); out-of-range items re-read a valid one
+    ob_u32x4 wreg[MT][KV];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int t = blockIdx.x + j * G;
+        const int t = blockIdx.x + min(j, my_tiles - 1) * G;
         const int p = t >= tile_base[2] ? 2 : (t >= tile_base[1] ? 1 : 0);
 #pragma unroll
-        for (int ci = 0; ci < PT; ++ci) {
-            if (j < my_tiles && ci < per_tile)
-                wreg[j][ci] = ob_dec_load_w(A.p[p], (t - tile_base[p]) << 4, wave + ci * OB_DEC_WAVES, lane);
-            else
-                wreg[j][ci] = (ob_u32x4){0u, 0u, 0u, 0u};
+        for (int ci = 0; ci < KV; ++ci) {
+#ifdef OB_PROFILE_ABLATE
+            if (A.ablate == 2 || A.ablate == 3) { wreg[j][ci] = (ob_u32x4){0x12345678u + lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x55aa55aau}; continue; }
+#endif
+            wreg[j][ci] = ob_dec_load_w<ALIGNED>(OB_SEL(p, w), OB_SEL(p, N), K, OB_SEL(p, ldw), (t - tile_base[p]) << 4,
+                                                 min(wave + ci * OB_DEC_WAVES, nchunks - 1), lane);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);      // nothing above may sink below, no use may rise above
 
-    // 2. prologue (statistics + activations into LDS) while the weights are in flight
-    ob_dec_prologue(A, lds_a, red, Kpad);
+    // ---- 2. prologue arithmetic in the reference's op order; fp16 tensor ops are native packed
+    //         fp16 instructions (contraction off: every op rounds once, as torch does) -------------
+    ob_half8 xh[KV];
+    if (PRO == OB_P_PLAIN) {
+#pragma unroll
+        for (int v = 0; v < KV; ++v) xh[v] = v0[v];
+    } else if (PRO == OB_P_SWIGLU) {
+        const float c0 = (float)c0h, c1 = (float)c1h;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            if (valid[v]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float dg = (float)v0[v][i] - c0, du = (float)v1[v][i] - c1;
+                    s[0] += dg; s[1] = fmaf(dg, dg, s[1]); s[2] += du; s[3] = fmaf(du, du, s[3]);
+                }
+            }
+        }
+        ob_block_sum_n<4>(s, red);
+        float mg, rg, mu, ru;
+        ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
+        ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            ob_half8 sg, up;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gate = (float)(_Float16)(((float)v0[v][i] - mg) * rg);      // LayerNorm(gate) -> fp16
+                up[i] = (_Float16)(((float)v1[v][i] - mu) * ru);                        // LayerNorm(up)   -> fp16
+                sg[i] = (_Float16)(gate / (1.0f + __expf(-gate)));                      // silu            -> fp16
+            }
+            xh[v] = sg * up;                                    // act_fn(gate) * up, modeling_bitllama.py:257
+        }
+    } else {
+        ob_half8 hv[KV];
+        if (PRO == OB_P_RES_LN_RMS) {
+            const float c0 = (float)c0h;
+            float s[2] = {0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                if (valid[v]) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float d = (float)v0[v][i] - c0; s[0] += d; s[1] = fmaf(d, d, s[1]); }
+                }
+            }
+            ob_block_sum_n<2>(s, red);
+            float mean, rstd;
+            ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                ob_half8 ln;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ln[i] = (_Float16)(((float)v0[v][i] - mean) * rstd);
+                hv[v] = v1[v] + ln;                 // residual + hidden_states, modeling_bitllama.py:912,918
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < KV; ++v) hv[v] = v1[v];
+        }
+        // RMSNorm (modeling_bitllama.py:76-81): fp32 variance, x * rsqrt -> fp16, weight * that -> fp16
+        float ss[1] = {0.f};
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            if (valid[v]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const ob_half2 pr = {hv[v][2 * i], hv[v][2 * i + 1]};
+                    ss[0] = __builtin_amdgcn_fdot2(pr, pr, ss[0], false);
+                }
+            }
+        }
+        ob_block_sum_n<1>(ss, red + 64);
+        const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            ob_half8 t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = (_Float16)((float)hv[v][i] * rs);
+            xh[v] = v2[v] * t;
+            if (blockIdx.x == 0 && A.hres_out && valid[v])
+                *reinterpret_cast<ob_half8 *>(A.hres_out + vbase[v]) = hv[v];
+        }
+    }
+    // a_p = fp16(x * h_p)  (bitnet.py:113), zero padding up to Kpad
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (p < nproj) {
+            _Float16 *dst = lds_a + (size_t)p * Kpad;
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                const int base = (v * OB_DEC_THREADS + tid) * 8;
+                if (base < Kpad) {
+                    ob_half8 o = xh[v] * hp[p][v];
+                    if (!valid[v]) o = (ob_half8)(_Float16)0;
+                    *reinterpret_cast<ob_half8 *>(dst + base) = o;
+                }
+            }
+        }
+    }
     __syncthreads();
 
-    // 3. MFMA
+    // ---- 3. MFMA ---------------------------------------------------------------------------------
     ob_float4 acc[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -337,13 +362,20 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         const int p = t >= tile_base[2] ? 2 : (t >= tile_base[1] ? 1 : 0);
         const _Float16 *ap = lds_a + (size_t)p * Kpad;
 #pragma unroll
-        for (int ci = 0; ci < PT; ++ci) {
-            if (j < my_tiles && ci < per_tile)
+        for (int ci = 0; ci < KV; ++ci) {
+            if (j < my_tiles && ci < per_tile) {
+#ifdef OB_PROFILE_ABLATE
+                if (A.ablate == 1 || A.ablate == 3) {     // no MFMA / expansion: keep the loaded words alive
+                    acc[j][0] += __uint_as_float((wreg[j][ci][0] ^ wreg[j][ci][1] ^ wreg[j][ci][2] ^ wreg[j][ci][3]) & 0x3fffffffu);
+                    continue;
+                }
+#endif
                 ob_dec_chunk(wreg[j][ci], ap + (size_t)(wave + ci * OB_DEC_WAVES) * 512, gq, acc[j]);
+            }
         }
     }
 
-    // 4. cross-wave reduction: column 0 of the result (lanes 0,16,32,48 hold rows 4*gq .. 4*gq+3)
+    // ---- 4. cross-wave reduction: column 0 of the result (lanes 0,16,32,48 hold rows 4*gq..4*gq+3)
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         if (j < my_tiles && (lane & 15) == 0) {
@@ -352,17 +384,15 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < my_tiles * 16) {
-        const int j = threadIdx.x >> 4, r = threadIdx.x & 15;
+    if (fin && n_raw < N_out) {
+        const int j = tid >> 4, r = tid & 15;
         float z = 0.f;
 #pragma unroll
         for (int w = 0; w < OB_DEC_WAVES; ++w) z += lds_red[((j * OB_DEC_WAVES + w) << 4) + r];
-        const int t = blockIdx.x + j * G;
-        const int p = t >= tile_base[2] ? 2 : (t >= tile_base[1] ? 1 : 0);
-        const int n = ((t - tile_base[p]) << 4) + r;
-        if (n < A.p[p].N)       // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
-            A.p[p].u[n] = (_Float16)(ob_round_h(z) * (float)A.p[p].g[n]);
+        // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
+        u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);
     }
+#undef OB_SEL
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,20 +413,36 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
     const int head = blockIdx.x, kvh = head / (H / Hkv);
-    const int pos = *A.pos;
-    const int L = pos + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *red = reinterpret_cast<float *>(smem);                    // 6*16 floats
+    float *red = reinterpret_cast<float *>(smem);                    // 2 slots: 6*16 + 16 floats
     _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);         // [D]
     _Float16 *k_s = q_s + D;                                         // [D] new key (post RoPE)
     _Float16 *v_s = k_s + D;                                         // [D] new value
     _Float16 *tmp = v_s + D;                                         // [2*D] pre-RoPE q, k
     float *sc = reinterpret_cast<float *>(tmp + 2 * D);              // [max_len] scores / probs
-    float *po = sc + A.max_len;                                      // [4][D] partial outputs
+    float *po = sc + A.max_len;                                      // [16][D] partial outputs
+
+    // ---- loads first: position, LayerNorm inputs, rope row, and the first 256 cached keys ------
+    const int pos = *A.pos;
+    const int L = pos + 1;
+    const int NQ = H * D, NK = Hkv * D;
+    const _Float16 *kbase = A.kcache + (int64_t)kvh * A.max_len * D;
+    const _Float16 *vbase = A.vcache + (int64_t)kvh * A.max_len * D;
+    const int D8 = D >> 3;
+    ob_half8 kreg[16];
+    {
+        const _Float16 *kr = kbase + (int64_t)min(tid, max(pos - 1, 0)) * D;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const ob_half8 *>(kr + (i < D8 ? i : 0) * 8);
+    }
+    const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
+    const int dq = min(tid, D - 1);
+    const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
+    const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
+    __builtin_amdgcn_sched_barrier(0);
 
     // LayerNorm statistics of the three rows (each workgroup recomputes them)
-    const int NQ = H * D, NK = Hkv * D;
-    const float cq = (float)A.u_q[0], ck = (float)A.u_k[0], cv = (float)A.u_v[0];
+    const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int base = tid * 8; base < NQ; base += 256 * 8) {
         const ob_half8 t = *reinterpret_cast<const ob_half8 *>(A.u_q + base);
@@ -419,14 +465,14 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
 
     if (tid < D) {
-        tmp[tid] = (_Float16)ob_ln_apply((float)A.u_q[head * D + tid], mq, rq);
-        tmp[D + tid] = (_Float16)ob_ln_apply((float)A.u_k[kvh * D + tid], mk, rk);
-        v_s[tid] = (_Float16)ob_ln_apply((float)A.u_v[kvh * D + tid], mv, rv);
+        tmp[tid] = (_Float16)ob_ln_apply((float)uqh, mq, rq);
+        tmp[D + tid] = (_Float16)ob_ln_apply((float)ukh, mk, rk);
+        v_s[tid] = (_Float16)ob_ln_apply((float)uvh, mv, rv);
     }
     __syncthreads();
     if (tid < D) {
         // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16
-        const float c = (float)A.cos[(int64_t)pos * D + tid], sn = (float)A.sin[(int64_t)pos * D + tid];
+        const float c = (float)cosh_, sn = (float)sinh_;
         const int half = D >> 1;
         const float qr = tid < half ? -(float)tmp[tid + half] : (float)tmp[tid - half];
         const float kr = tid < half ? -(float)tmp[D + tid + half] : (float)tmp[D + tid - half];
@@ -442,27 +488,33 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     __syncthreads();
 
     // scores: one position per thread; fp32 dot -> fp16 (matmul output) -> / sqrt(D) -> fp16 (:546)
-    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
     const float sqrt_d = sqrtf((float)D);
-    (void)inv_sqrt_d;
-    const _Float16 *kbase = A.kcache + (int64_t)kvh * A.max_len * D;
     float lmax = -INFINITY;
     for (int p = tid; p < L; p += 256) {
         float dot = 0.f;
         if (p == pos) {
-            for (int d = 0; d < D; d += 8) {
-                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(k_s + d);
-                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + d);
+            for (int i = 0; i < D8; ++i) {
+                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(k_s + 8 * i);
+                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dot += (float)qq[i] * (float)kk[i];
+                for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kk[e];
+            }
+        } else if (p < 256) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < D8) {
+                    const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kreg[i][e];
+                }
             }
         } else {
             const _Float16 *kr = kbase + (int64_t)p * D;
-            for (int d = 0; d < D; d += 8) {
-                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(kr + d);
-                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + d);
+            for (int i = 0; i < D8; ++i) {
+                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(kr + 8 * i);
+                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dot += (float)qq[i] * (float)kk[i];
+                for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kk[e];
             }
         }
         const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
@@ -471,42 +523,43 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     }
     // softmax in fp32 (:562), probabilities rounded to fp16
     lmax = ob_wave_max(lmax);
+    if (lane == 0) red[96 + wave] = lmax;
     __syncthreads();
-    if (lane == 0) red[wave] = lmax;
-    __syncthreads();
-    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float gmax = fmaxf(fmaxf(red[96], red[97]), fmaxf(red[98], red[99]));
     float ls[1] = {0.f};
     for (int p = tid; p < L; p += 256) {
         const float e = __expf(sc[p] - gmax);
         sc[p] = e;
         ls[0] += e;
     }
-    ob_block_sum_n<1>(ls, red);
+    ob_block_sum_n<1>(ls, red + 112);
     const float inv_l = 1.0f / ls[0];
     for (int p = tid; p < L; p += 256) sc[p] = ob_round_h(sc[p] * inv_l);
     __syncthreads();
 
-    // out = P . V: wave w takes positions p = w mod 4, lanes take dims (2 per lane up to D = 128)
-    const _Float16 *vbase = A.vcache + (int64_t)kvh * A.max_len * D;
+    // out = P . V: thread = (position group pg of 16, 8-dim slice ds of 16); 16-byte V loads
+    const int ds = tid & 15, pg = tid >> 4;
     for (int d0 = 0; d0 < D; d0 += 128) {
-        const int d = d0 + 2 * lane;
-        float o0 = 0.f, o1 = 0.f;
+        const int d = d0 + 8 * ds;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (d < D) {
-            for (int p = wave; p < L; p += 4) {
+#pragma unroll 4
+            for (int p = pg; p < L; p += 16) {
                 const float pr = sc[p];
-                ob_half2 vv;
-                if (p == pos) vv = *reinterpret_cast<const ob_half2 *>(v_s + d);
-                else vv = *reinterpret_cast<const ob_half2 *>(vbase + (int64_t)p * D + d);
-                o0 += pr * (float)vv[0];
-                o1 += pr * (float)vv[1];
+                const ob_half8 vv = (p == pos) ? *reinterpret_cast<const ob_half8 *>(v_s + d)
+                                               : *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
             }
-            po[wave * D + d] = o0;
-            po[wave * D + d + 1] = o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) po[pg * D + d + e] = o[e];
         }
     }
     __syncthreads();
     if (tid < D) {
-        const float o = po[tid] + po[D + tid] + po[2 * D + tid] + po[3 * D + tid];
+        float o = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) o += po[g2 * D + tid];
         A.out[head * D + tid] = (_Float16)o;
     }
 }
@@ -565,7 +618,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
                 }
             }
         }
-        ob_block_sum_n<1>(ss, red);
+        ob_block_sum_n<1>(ss, red + 32);
         const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < OB_DEC_MAXV; ++v) {
@@ -584,23 +637,43 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
         }
     }
     __syncthreads();
-    // rows: wave-strided over the vocabulary; 8 halves per lane per 512-wide step
+    // rows: two rows per wave iteration, 4 x 16-byte loads per row in flight per lane
     float best = -INFINITY;
     int besti = 0x7fffffff;
     const int gw = blockIdx.x * OB_DEC_WAVES + wave, nw = gridDim.x * OB_DEC_WAVES;
-    for (int row = gw; row < A.V; row += nw) {
-        const _Float16 *wr = A.lm_w + (int64_t)row * K;
-        float acc = 0.f;
-        for (int k = lane * 8; k < K; k += 512) {
-            const ob_half8 wv = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(wr + k));
-            const ob_half8 xv = *reinterpret_cast<const ob_half8 *>(x_s + k);
+    for (int row = gw; row < A.V; row += 2 * nw) {
+        const int rowb = row + nw;
+        const bool hasb = rowb < A.V;
+        const _Float16 *wa = A.lm_w + (int64_t)row * K;
+        const _Float16 *wb = A.lm_w + (int64_t)(hasb ? rowb : row) * K;
+        float acca = 0.f, accb = 0.f;
+        for (int k0 = lane * 8; k0 < K; k0 += 2048) {
+            ob_half8 ra[4], rb[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += (float)wv[i] * (float)xv[i];
+            for (int i = 0; i < 4; ++i) {
+                const int k = min(k0 + 512 * i, K - 8);
+                ra[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(wa + k));
+                rb[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(wb + k));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 512 * i;
+                if (k < K) {
+                    const ob_half8 xv = *reinterpret_cast<const ob_half8 *>(x_s + k);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { acca += (float)ra[i][e] * (float)xv[e]; accb += (float)rb[i][e] * (float)xv[e]; }
+                }
+            }
         }
-        acc = ob_wave_sum(acc);
-        const float lg = ob_round_h(acc);
-        if (lane == 0) A.logits[row] = (_Float16)lg;
-        if (lg > best || (lg == best && row < besti)) { best = lg; besti = row; }
+        acca = ob_wave_sum(acca);
+        accb = ob_wave_sum(accb);
+        const float la = ob_round_h(acca), lb = ob_round_h(accb);
+        if (lane == 0) {
+            A.logits[row] = (_Float16)la;
+            if (hasb) A.logits[rowb] = (_Float16)lb;
+        }
+        if (la > best || (la == best && row < besti)) { best = la; besti = row; }
+        if (hasb && (lb > best || (lb == best && rowb < besti))) { best = lb; besti = rowb; }
     }
     // workgroup argmax (first index on ties)
     __syncthreads();

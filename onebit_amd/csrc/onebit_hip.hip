@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/onebit.h"
 #include "ob_linear.h"
@@ -275,39 +276,85 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
-template <int PT, int MT>
+template <int KV, int MT, bool ALIGNED, int PRO>
 static void ob_launch_dec_gemv_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<PT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<KV, MT, ALIGNED, PRO>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<PT, MT>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MT, ALIGNED, PRO>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
 }
 
-static int ob_launch_dec_gemv(const ObGemvArgs &a, hipStream_t s)
+template <int KV, int MT, bool ALIGNED>
+static void ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
+    switch (a.prologue) {
+    case OB_P_PLAIN: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_PLAIN>(a, G, lds, s); break;
+    case OB_P_EMBED_RMS: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_EMBED_RMS>(a, G, lds, s); break;
+    case OB_P_RES_LN_RMS: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_RES_LN_RMS>(a, G, lds, s); break;
+    default: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_SWIGLU>(a, G, lds, s); break;
+    }
+}
+
+static int ob_ablate_mode()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("OB_ABLATE");
+        mode = e ? atoi(e) : 0;
+        if (mode) fprintf(stderr, "[onebit] OB_ABLATE=%d (profiling mode, results are garbage)\n", mode);
+    }
+    return mode;
+}
+
+static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
+{
+    ObGemvArgs a = a_in;
+    a.ablate = ob_ablate_mode();
     int ntiles = 0;
     for (int p = 0; p < a.nproj; ++p) ntiles += (a.p[p].N + 15) / 16;
     const int Kpad = (a.K + 511) & ~511;
     const int nchunks = Kpad / 512;
-    const int pt_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;
-    const int PT = pt_need <= 1 ? 1 : (pt_need <= 2 ? 2 : 4);
-    const int mt_max = PT == 1 ? 8 : (PT == 2 ? 4 : 2);
+    const int kv_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;       // = ceil(K / 4096)
+    const int KV = kv_need <= 1 ? 1 : (kv_need <= 2 ? 2 : 4);
+    bool aligned = a.K % 128 == 0;
+    for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
+    if (!aligned && KV != 1)
+        return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
+    const int mt_max = KV == 1 ? 8 : (KV == 2 ? 4 : 2);
     int G = ob_cu_count();
     if (ntiles < G) G = ntiles;
     if ((ntiles + G - 1) / G > mt_max) G = (ntiles + mt_max - 1) / mt_max;
     const int mt_need = (ntiles + G - 1) / G;
-    const int MT = mt_need <= 1 ? 1 : (mt_need <= 2 ? 2 : (mt_need <= 4 ? 4 : 8));
-    const size_t lds = (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 128 * 4;
-    if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: LDS need %zu > 160 KiB", lds);
-#define OB_CASE(P, M) if (PT == P && MT == M) { ob_launch_dec_gemv_t<P, M>(a, G, lds, s); return ob_launch_status("decode_step(gemv)"); }
-    OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 4) OB_CASE(1, 8)
-    OB_CASE(2, 1) OB_CASE(2, 2) OB_CASE(2, 4)
-    OB_CASE(4, 1) OB_CASE(4, 2)
+    // instantiated tile counts: 1 2 3 4 6 8 (KV = 1), 1 2 4 (KV = 2), 1 2 (KV = 4)
+    int MT = mt_need;
+    if (KV == 1) MT = mt_need <= 4 ? mt_need : (mt_need <= 6 ? 6 : 8);
+    else if (KV == 2) MT = mt_need <= 2 ? mt_need : 4;
+    const size_t lds = (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
+    if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
+#define OB_CASE(P, M)                                                              \
+    if (KV == P && MT == M) {                                                      \
+        ob_launch_dec_gemv_p<P, M, true>(a, G, lds, s);                            \
+        return ob_launch_status("decode gemv");                                    \
+    }
+#define OB_CASE_U(M)                                                               \
+    if (MT == M) {                                                                 \
+        ob_launch_dec_gemv_p<1, M, false>(a, G, lds, s);                           \
+        return ob_launch_status("decode gemv");                                    \
+    }
+    if (aligned) {
+        OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 3) OB_CASE(1, 4) OB_CASE(1, 6) OB_CASE(1, 8)
+        OB_CASE(2, 1) OB_CASE(2, 2) OB_CASE(2, 4)
+        OB_CASE(4, 1) OB_CASE(4, 2)
+    } else {
+        OB_CASE_U(1) OB_CASE_U(2) OB_CASE_U(3) OB_CASE_U(4) OB_CASE_U(6) OB_CASE_U(8)
+    }
 #undef OB_CASE
-    return ob_fail(ONEBIT_E_SHAPE, "decode_step: no kernel instance for PT=%d MT=%d", PT, MT);
+#undef OB_CASE_U
+    return ob_fail(ONEBIT_E_SHAPE, "decode gemv: no kernel instance for KV=%d MT=%d", KV, MT);
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
@@ -380,7 +427,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
-        const size_t attn_lds = 512 + (size_t)10 * D + (size_t)4 * m->max_len + (size_t)16 * D;
+        const size_t attn_lds = 512 + (size_t)10 * D + (size_t)4 * m->max_len + (size_t)64 * D;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
         hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(256), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step(attn)"))) return rc;

@@ -101,3 +101,81 @@ def test_engine_matches_module_path(cfgkw, steps):
         srt = np.sort(ref[i])
         if i < steps - 1 and srt[-1] - srt[-2] < 8e-3 * np.abs(ref).max():
             break                                            # margin within noise: later tokens may diverge
+
+
+def _ref_u(mod, x):
+    """pre-LayerNorm output of a BitLinearInf through the module path (its own HIP kernel, already
+    pinned against the oracle): u = fp16(fp16(W.(h*x)) * g)."""
+    ln, mod.layernorm = mod.layernorm, torch.nn.Identity()
+    try:
+        return mod(x[None])[0]
+    finally:
+        mod.layernorm = ln
+
+
+@pytest.mark.parametrize("H,I", [(4096, 11008), (5120, 13824), (512, 1408), (128, 352)])
+def test_fused_gemv_each_prologue(H, I):
+    """onebit_fused_gemv launch by launch (the building blocks of onebit_decode_step) against the same
+    math assembled from torch fp16 ops in the reference's order + the module-path BitLinearInf."""
+    from onebit_amd.engine import PRO_EMBED_RMS, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU, fused_gemv
+    from onebit_amd.llama import LlamaRMSNorm, OneBitLlamaConfig, build_synthetic_model
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=64, hidden_size=H, intermediate_size=I, num_hidden_layers=1,
+                            num_attention_heads=H // 64, max_position_embeddings=16)
+    model = build_synthetic_model(cfg, seed=5, device=dev)
+    layer = model.model.layers[0]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    f16 = torch.float16
+    rnd = lambda n, s=1.0: (s * torch.randn(n, generator=g)).to(f16).to(dev)
+    rms_w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(f16).to(dev)
+    norm = LlamaRMSNorm(H, eps=1e-6, dtype=f16).to(dev)
+    norm.weight.data = rms_w
+    ln = lambda v: F.layer_norm(v, (v.numel(),), eps=1e-5)
+
+    def check(got, ref, tag):
+        got, ref = got.float(), ref.float()
+        ulp = ref.abs().clamp_min(2.0 ** -14) * 2.0 ** -10
+        bad = ((got - ref).abs() > 2.001 * ulp)
+        # inputs of the GEMV may differ by an fp16 ulp in a few elements (rsqrt / exp approximations),
+        # which moves every output slightly: bound the aggregate instead of each element
+        rel = (got - ref).norm() / ref.norm()
+        gross = ((got - ref).abs() > 0.02 * ref.abs().clamp_min(0.1)).nonzero().flatten()
+        assert rel <= 1e-3, (tag, float(rel), int(gross.numel()), gross[:32].tolist())
+        assert bad.float().mean() <= 0.05, (tag, float(bad.float().mean()))
+
+    a, mlp = layer.self_attn, layer.mlp
+    # PLAIN: o_proj
+    x = rnd(H)
+    out = torch.empty(H, device=dev, dtype=f16)
+    fused_gemv([a.o_proj], [out], PRO_PLAIN, xin=x)
+    check(out, _ref_u(a.o_proj, x), "plain")
+    # RES_LN_RMS: q, k, v (3 projections) and gate, up (2)
+    hres, u_prev = rnd(H), rnd(H, 3.0) + 0.7
+    r = hres + ln(u_prev)
+    xn = norm(r)
+    outs = [torch.empty(H, device=dev, dtype=f16) for _ in range(3)]
+    hout = torch.empty(H, device=dev, dtype=f16)
+    fused_gemv([a.q_proj, a.k_proj, a.v_proj], outs, PRO_RES_LN_RMS, hres_in=hres, u_prev=u_prev, hres_out=hout, rms_w=rms_w)
+    # the residual stream written by workgroup 0: torch's LayerNorm statistics may differ in the last fp32 bit
+    assert (hout.float() - r.float()).abs().max() <= 2.0 ** -9 * max(1.0, float(r.abs().max()))
+    assert (hout != r).float().mean() <= 0.01
+    for o, m, n in zip(outs, (a.q_proj, a.k_proj, a.v_proj), "qkv"):
+        check(o, _ref_u(m, xn), "res_ln_rms " + n)
+    og, ou = torch.empty(I, device=dev, dtype=f16), torch.empty(I, device=dev, dtype=f16)
+    fused_gemv([mlp.gate_proj, mlp.up_proj], [og, ou], PRO_RES_LN_RMS, hres_in=hres, u_prev=u_prev, hres_out=hout, rms_w=rms_w)
+    check(og, _ref_u(mlp.gate_proj, xn), "gate")
+    check(ou, _ref_u(mlp.up_proj, xn), "up")
+    # EMBED_RMS
+    tok = torch.tensor([7], device=dev, dtype=torch.int32)
+    emb = model.model.embed_tokens.weight
+    fused_gemv([a.q_proj, a.k_proj, a.v_proj], outs, PRO_EMBED_RMS, embed=emb, token=tok, hres_out=hout, rms_w=rms_w)
+    assert torch.equal(hout, emb[7])
+    check(outs[0], _ref_u(a.q_proj, norm(emb[7])), "embed q")
+    check(outs[2], _ref_u(a.v_proj, norm(emb[7])), "embed v")
+    # SWIGLU: down
+    ug, uu = rnd(I, 2.0) - 0.3, rnd(I, 0.5) + 0.2
+    act = F.silu(ln(ug)) * ln(uu)
+    od = torch.empty(H, device=dev, dtype=f16)
+    fused_gemv([mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu)
+    check(od, _ref_u(mlp.down_proj, act), "swiglu")

@@ -1,0 +1,44 @@
+"""Per-launch wall time of the fused decode GEMV launches (graph replay, HIP events), per OB_ABLATE mode.
+Usage: OB_ABLATE=m python tools/gemv_probe.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+from onebit_amd.engine import fused_gemv, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU
+
+dev = torch.device("cuda:0")
+cfg = OneBitLlamaConfig(num_hidden_layers=8)
+model = build_synthetic_model(cfg, seed=1, device=dev)
+H, I = cfg.hidden_size, cfg.intermediate_size
+f16 = torch.float16
+hres, uprev, hout = (torch.randn(H, device=dev).to(f16) for _ in range(3))
+ug, uu = torch.randn(I, device=dev).to(f16), torch.randn(I, device=dev).to(f16)
+oq, ok, ov, oo, og, ou, od = (torch.empty(n, device=dev, dtype=f16) for n in (H, H, H, H, I, I, H))
+L = list(model.model.layers)
+
+def chain(kind):
+    for l in L:
+        if kind == "o":
+            fused_gemv([l.self_attn.o_proj], [oo], PRO_PLAIN, xin=hres)
+        elif kind == "qkv":
+            fused_gemv([l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj], [oq, ok, ov], PRO_RES_LN_RMS,
+                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.input_layernorm.weight)
+        elif kind == "gateup":
+            fused_gemv([l.mlp.gate_proj, l.mlp.up_proj], [og, ou], PRO_RES_LN_RMS,
+                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.post_attention_layernorm.weight)
+        else:
+            fused_gemv([l.mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu)
+
+out = []
+for kind in ("o", "qkv", "gateup", "down"):
+    chain(kind); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain(kind)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    out.append("%s %.2f" % (kind, e0.elapsed_time(e1) * 1e3 / (20 * len(L))))
+print("OB_ABLATE=%s us/launch:" % os.environ.get("OB_ABLATE", "0"), "  ".join(out))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table.
-Usage: python tools_prof_summary.py gpurun_out/prof/x_results.db > profiles/x_kernel_stats.txt"""
+Usage: python tools/prof_summary.py gpurun_out/prof/x_results.db > profiles/x_kernel_stats.txt"""
 import sqlite3
 import sys
 
