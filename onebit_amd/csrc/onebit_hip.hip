@@ -10,6 +10,7 @@
 #include "ob_linear.h"
 #include "ob_pack.h"
 #include "ob_decode.h"
+#include "ob_gemm.h"
 
 static thread_local char g_err[256] = "";
 
@@ -117,6 +118,14 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                            const void *h, const void *g, void *u, float *zp, int64_t T, int64_t K,
                            int64_t N, hipStream_t s)
 {
+    if (T > 16) {       // batched prefill: 128 x 128 MFMA tiles, weights expanded once per 4 token tiles
+        const int nbn = (int)((N + OB_GB_N - 1) / OB_GB_N), nbt = (int)((T + OB_GB_T - 1) / OB_GB_T);
+        hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL>), dim3((unsigned)(nbn * nbt)), dim3(256), 0, s,
+                           (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
+                           (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
+                           (int)N, nbn, nbt);
+        return;
+    }
     const int fast = (ldw_bytes % 16 == 0) && ob_aligned(packed, 16) && (ldx % 8 == 0);
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((T + 15) / 16));
     const int64_t units = fast ? (K + 511) / 512 : (K + 127) / 128;

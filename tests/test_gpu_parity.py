@@ -107,6 +107,9 @@ SHAPES = [
     ((17,), 1376, 100, False),        # two token tiles, N not a multiple of 16
     ((33,), 512, 17, False),
     ((4,), 32, 1, False),             # single row, single word
+    ((2, 100), 4096, 384, False),     # tiled MFMA GEMM (T > 16): 2 token tiles, 3 row tiles
+    ((129,), 256, 130, True),         # GEMM with ragged token and row tiles
+    ((40,), 352, 48, False),          # GEMM, K % 128 != 0 (partial last k-step)
     ((2,), 688, 48, False),           # K % 32 != 0 -> generic kernel
     ((5,), 40, 9, True),
 ]
@@ -247,3 +250,28 @@ def test_k_sharded_partials_match_full(dev, coracle):
                                     T, N, 0, 1e-5, 0, _stream_ptr(dev))
     _lib.check(rc, "scale_layernorm")
     _check_f16(y.cpu().numpy(), u.cpu().numpy(), y_ref, u_ref, "ksharded")
+
+
+def test_prefill_gemm_matches_single_token_path(dev):
+    """Full-width prefill property (BASELINE config 3 shape, fewer tokens): every token of a batched
+    call (tiled GEMM kernel) agrees with the same token pushed alone through the T <= 16 kernel."""
+    from onebit_amd import BitLinearInf
+    K, N, T = 4096, 11008, 300
+    g = torch.Generator(device="cpu").manual_seed(21)
+    m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
+    m.weight.data = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8).to(dev)
+    m.input_factor.data = (0.1 * (0.5 + torch.rand(K, generator=g))).half().to(dev)
+    m.weight_scale.data = (0.1 * (0.5 + torch.rand(N, generator=g))).half().to(dev)
+    x = torch.randn(T, K, generator=g).half().to(dev)
+    y = m(x)
+    m.layernorm = torch.nn.Identity()
+    u = m(x)
+    for t in (0, 15, 127, 128, 255, 299):
+        u1 = m(x[t:t + 1])
+        d = (u[t].float() - u1[0].float()).abs()
+        ulp = u1[0].float().abs().clamp_min(2.0 ** -14) * FP16_ULP
+        assert (d <= 2.001 * ulp).all(), t
+        assert (u[t] != u1[0]).float().mean() <= 0.02, t
+    m.layernorm = torch.nn.LayerNorm(N, elementwise_affine=False)
+    y1 = m(x[128:129])
+    assert (y[128].float() - y1[0].float()).abs().max() <= 2.5 * FP16_ULP * max(1.0, float(y1.abs().max()))
