@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true")
     return ap.parse_args()
 
 
@@ -123,6 +124,49 @@ def measure_roofline(model, dev):
             "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(us, 3), "launches": n,
             "distinct_weight_sets": len(layers),
             "note": "HIP events around graph replays of back-to-back launches: includes the kernel boundary"}
+
+
+def measure_prefill_sharded(cfg, dev, world, rank):
+    """K-sharded (hidden-dim sharded) prefill of one 1-bit layer, hidden -> intermediate, T = 8 x 2048
+    tokens (BASELINE configs[2] shape): every rank holds K/world columns of the packed matrix,
+    computes fp32 partial sums on its MFMA kernel, reduce-scatters them over tokens (RCCL),
+    applies g + LayerNorm to its rows and all-gathers the fp16 result (onebit_amd/sharded.py)."""
+    import torch.distributed as dist
+    from onebit_amd.sharded import k_sharded_forward, shard_k
+    K, N, T = cfg.hidden_size, cfg.intermediate_size, 8 * 2048
+    g = torch.Generator(device=dev).manual_seed(77)
+    W = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8, device=dev).view(torch.int8)
+    h = (0.1 * (0.5 + torch.rand(K, generator=g, device=dev))).half()
+    gs = (0.1 * (0.5 + torch.rand(N, generator=g, device=dev))).half()
+    x = torch.randn(T, K, generator=g, device=dev).half()
+    shard = shard_k(W, h, gs, None, rank, world)
+    created = False
+    if world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    for _ in range(2):
+        k_sharded_forward(shard, x, mode="rs_ag")
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        k_sharded_forward(shard, x, mode="rs_ag")
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    dt = (time.perf_counter() - t0) / n
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if created:
+        dist.destroy_process_group()
+    return {"layer": "%d->%d" % (K, N), "tokens": T, "k_shards": world, "exchange": "reduce_scatter(fp32)+all_gather(fp16)",
+            "ms_per_call": round(dt * 1e3, 3), "tokens_per_s": round(T / dt, 1),
+            "TFLOPs": round(2.0 * T * K * N / dt / 1e12, 1), "mfma_peak_TFLOPs": 2500.0 * world,
+            "frac_of_mfma_peak": round(2.0 * T * K * N / dt / 1e12 / (2500.0 * world), 4)}
 
 
 def measure_cpu_baseline(cfg):
@@ -218,6 +262,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    prefill = None
+    if not args.no_prefill:
+        prefill = measure_prefill_sharded(cfg, dev, world, rank)
     roof = cpu = None
     if rank == 0:
         if not args.no_roofline:
@@ -244,7 +291,7 @@ def main():
             "token_hbm": {"algorithmic_bytes_per_token": tok_b, "onebit_layer_bytes_per_token": star_b,
                           "achieved_GBps_whole_token": round(tok_b * per_gpu_tok_s / 1e9, 1),
                           "frac_of_8TBps": round(tok_b * per_gpu_tok_s / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "prefill_k_sharded": prefill,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -275,3 +275,38 @@ def test_prefill_gemm_matches_single_token_path(dev):
     m.layernorm = torch.nn.LayerNorm(N, elementwise_affine=False)
     y1 = m(x[128:129])
     assert (y[128].float() - y1[0].float()).abs().max() <= 2.5 * FP16_ULP * max(1.0, float(y1.abs().max()))
+
+
+def test_k_sharded_forward_hip_world1(dev):
+    """The K-sharded driver with the HIP callbacks over RCCL at world_size 1 (the only size a 1-GPU
+    box offers; sizes 2/3 are covered on CPU with gloo in tests/test_sharded_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from onebit_amd import BitLinearInf
+    from onebit_amd.sharded import k_sharded_forward, shard_k
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        K, N, T = 1024, 272, 37
+        g = torch.Generator(device="cpu").manual_seed(8)
+        m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
+        m.weight.data = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8).to(dev)
+        m.input_factor.data = (0.1 * (0.5 + torch.rand(K, generator=g))).half().to(dev)
+        m.weight_scale.data = (0.1 * (0.5 + torch.rand(N, generator=g))).half().to(dev)
+        x = torch.randn(T, K, generator=g).half().to(dev)
+        ref = m(x)
+        for mode in ("rs_ag", "allreduce"):
+            # emulate 4 K-shards on one device: sum the partials by hand through the same callbacks
+            from onebit_amd.sharded import hip_epilogue, hip_partial
+            z = sum(hip_partial(shard_k(m.weight.data, m.input_factor.data, m.weight_scale.data, None, r, 4, copy=(r % 2 == 0)),
+                                x[:, r * 256:(r + 1) * 256]) for r in range(4))
+            y4 = hip_epilogue(shard_k(m.weight.data, m.input_factor.data, m.weight_scale.data, None, 0, 4), z, torch.float16)
+            assert (y4.float() - ref.float()).abs().max() <= 2.5 * FP16_ULP * max(1.0, float(ref.abs().max()))
+            y = k_sharded_forward(shard_k(m.weight.data, m.input_factor.data, m.weight_scale.data, None, 0, 1), x, mode=mode)
+            assert (y.float() - ref.float()).abs().max() <= 2.5 * FP16_ULP * max(1.0, float(ref.abs().max()))
+    finally:
+        if created:
+            dist.destroy_process_group()

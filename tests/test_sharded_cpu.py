@@ -1,0 +1,111 @@
+"""World-size-2 (and 3) gloo tests of the K-sharded layer's host logic on CPU: sharding plan,
+partial-sum exchange placed before the LayerNorm, both exchange modes, ragged token counts.
+The compute callbacks are oracle-backed here (test infrastructure); on a GPU box the same control
+flow runs with the HIP callbacks over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from onebit_amd.sharded import k_range, k_sharded_forward, shard_k
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _np_partial(shard, x_slice):
+    from oracle.oracle import np_int8_to_fp
+    W = np_int8_to_fp(shard.weight.numpy(), np.float64)
+    xs = x_slice.numpy()
+    if xs.dtype == np.float16:
+        a = (xs.astype(np.float32) * shard.input_factor.numpy().astype(np.float32)[None]).astype(np.float16)
+    else:
+        a = xs * shard.input_factor.numpy()[None]
+    return torch.from_numpy((a.astype(np.float64) @ W.T).astype(np.float32))
+
+
+def _np_epilogue(shard, z, dtype, eps):
+    zf = z.numpy()
+    g = shard.weight_scale.numpy()
+    if dtype == torch.float16:
+        u = (zf.astype(np.float16).astype(np.float32) * g.astype(np.float32)[None]).astype(np.float16).astype(np.float64)
+    else:
+        u = (zf * g[None]).astype(np.float64)
+    mean = u.mean(-1, keepdims=True)
+    var = ((u - mean) ** 2).mean(-1, keepdims=True)
+    y = (u - mean) / np.sqrt(var + eps)
+    if shard.bias is not None:
+        y = y.astype(np.float16 if dtype == torch.float16 else np.float32).astype(np.float64) + shard.bias.numpy()[None]
+    return torch.from_numpy(y.astype(np.float16 if dtype == torch.float16 else np.float32))
+
+
+def _worker(rank, world, port, T, K, N, mode, dtype_name, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt = torch.float16 if dtype_name == "f16" else torch.float32
+        g = torch.Generator().manual_seed(5)                      # identical full tensors on every rank
+        W = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8)
+        h = (0.1 * (0.5 + torch.rand(K, generator=g))).to(dt)
+        gs = (0.1 * (0.5 + torch.rand(N, generator=g))).to(dt)
+        b = (0.1 * torch.randn(N, generator=g)).to(dt)
+        x = torch.randn(T, K, generator=g).to(dt)
+        shard = shard_k(W, h, gs, b, rank, world, copy=(rank % 2 == 0))   # exercise view and copy
+        assert shard.k0 % 32 == 0 and shard.k1 % 32 == 0
+        y = k_sharded_forward(shard, x, mode=mode, partial_fn=_np_partial, epilogue_fn=_np_epilogue)
+        assert y.shape == (T, N) and y.dtype == dt
+        # every rank ends with the same complete result
+        ys = [torch.empty_like(y) for _ in range(world)]
+        dist.all_gather(ys, y)
+        for other in ys:
+            assert torch.equal(other, y)
+        if rank == 0:
+            from oracle.oracle import COracle
+            c = COracle()
+            fn = c.forward_f16 if dt == torch.float16 else c.forward_f32
+            ref = fn(W.numpy(), x.numpy(), h.numpy(), gs.numpy(), b.numpy())
+            err = np.abs(y.numpy().astype(np.float32) - ref.astype(np.float32)).max()
+            out.put(float(err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,K,N,mode,dtype", [
+    (2, 5, 256, 48, "rs_ag", "f16"),          # T not divisible by world: padded reduce_scatter
+    (2, 4, 256, 48, "allreduce", "f16"),
+    (3, 7, 1376 // 32 * 32, 40, "rs_ag", "f32"),   # uneven K split (43 dwords over 3 ranks)
+])
+def test_k_sharded_forward_gloo(world, T, K, N, mode, dtype):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, K, N, mode, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    err = q.get(timeout=5)
+    assert err <= (4e-3 if dtype == "f16" else 2e-4), err
+
+
+def test_k_range_partition():
+    for K in (4096, 11008, 5120, 13824, 1376, 32):
+        for world in (1, 2, 3, 4, 8):
+            if K // 32 < world:
+                continue
+            edges = [k_range(K, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == K
+            for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+                assert a1 == b0 and a0 < a1
+            assert all(a % 32 == 0 and b % 32 == 0 for a, b in edges)
+    with pytest.raises(ValueError):
+        k_range(40, 0, 2)
