@@ -140,29 +140,25 @@ def measure_prefill_sharded(cfg, dev, world, rank):
     gs = (0.1 * (0.5 + torch.rand(N, generator=g, device=dev))).half()
     x = torch.randn(T, K, generator=g, device=dev).half()
     shard = shard_k(W, h, gs, None, rank, world)
-    created = False
-    if world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        created = True
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
     for _ in range(2):
         k_sharded_forward(shard, x, mode="rs_ag")
-    torch.cuda.synchronize(dev)
-    dist.barrier()
-    torch.cuda.synchronize(dev)
+    fence()
     n = 5
     t0 = time.perf_counter()
     for _ in range(n):
         k_sharded_forward(shard, x, mode="rs_ag")
-    torch.cuda.synchronize(dev)
-    dist.barrier()
+    fence()
     dt = (time.perf_counter() - t0) / n
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    if created:
-        dist.destroy_process_group()
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     return {"layer": "%d->%d" % (K, N), "tokens": T, "k_shards": world, "exchange": "reduce_scatter(fp32)+all_gather(fp16)",
             "ms_per_call": round(dt * 1e3, 3), "tokens_per_s": round(T / dt, 1),
             "TFLOPs": round(2.0 * T * K * N / dt / 1e12, 1), "mfma_peak_TFLOPs": 2500.0 * world,
@@ -293,9 +289,11 @@ def main():
                           "frac_of_8TBps": round(tok_b * per_gpu_tok_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roof, "cpu_baseline": cpu, "prefill_k_sharded": prefill,
         }
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)       # the one JSON line, last on stdout
 
 
 if __name__ == "__main__":

@@ -14,18 +14,33 @@ typedef int32_t ob_i32x4 __attribute__((ext_vector_type(4)));
 
 #define OB_WAVE 64
 
+// Wave64 reductions on the DPP network (row = 16 lanes): quad butterflies, row mirrors, then the two
+// row broadcasts; ~8 VALU instructions, no LDS crossbar traffic (ds_bpermute-based shuffles cost
+// ~100 cycles per step).  Every lane receives the result.
+#define OB_DPP_F(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
 __device__ __forceinline__ float ob_wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += OB_DPP_F(v, 0xB1, 0xF);     // quad_perm [1,0,3,2]
+    v += OB_DPP_F(v, 0x4E, 0xF);     // quad_perm [2,3,0,1]
+    v += OB_DPP_F(v, 0x141, 0xF);    // row_half_mirror
+    v += OB_DPP_F(v, 0x140, 0xF);    // row_mirror: every lane of a row holds the row sum
+    v += OB_DPP_F(v, 0x142, 0xA);    // row_bcast15 into rows 1, 3
+    v += OB_DPP_F(v, 0x143, 0xC);    // row_bcast31 into rows 2, 3: row 3 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float ob_wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    const int ninf = 0xff800000;
+#define OB_DPP_M(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    v = fmaxf(v, OB_DPP_M(v, 0xB1, 0xF));
+    v = fmaxf(v, OB_DPP_M(v, 0x4E, 0xF));
+    v = fmaxf(v, OB_DPP_M(v, 0x141, 0xF));
+    v = fmaxf(v, OB_DPP_M(v, 0x140, 0xF));
+    v = fmaxf(v, OB_DPP_M(v, 0x142, 0xA));
+    v = fmaxf(v, OB_DPP_M(v, 0x143, 0xC));
+#undef OB_DPP_M
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Block-wide sum through LDS; `red` holds >= (blockDim.x / 64) floats.  All threads get the result.

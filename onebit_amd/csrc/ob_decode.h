@@ -53,16 +53,19 @@ struct ObGemvArgs {
     const _Float16 *u_gate, *u_up; // SWIGLU: pre-LN gate / up [K]
     float rms_eps, ln_eps;
     int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
+    unsigned long long *dbg;       // profiling builds only: per-workgroup phase timestamps [grid][8]
 };
 
-// Block-wide sums of NV values through LDS.  `red` must be a slot (16*NV floats) not used by any
-// other reduction still in flight, so a single barrier suffices.
-template <int NV>
+// Block-wide sums of NV values through LDS.  `red` must be a slot (16*NV floats, 16-byte aligned)
+// not used by any other reduction still in flight, so a single barrier suffices.  NW (waves per
+// workgroup) is a compile-time constant: the partials of one value are two ds_read_b128, not a
+// loop of dependent scalar LDS reads (that loop cost ~1.7 us per reduction).
+template <int NV, int NW>
 __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
 {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = ob_wave_sum(v[i]);
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) red[i * 16 + wave] = v[i];
@@ -70,8 +73,12 @@ __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        float s = 0.f;
-        for (int w = 0; w < nw; ++w) s += red[i * 16 + w];
+        const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16);
+        float s = (a[0] + a[1]) + (a[2] + a[3]);
+        if (NW > 4) {
+            const ob_float4 b = *reinterpret_cast<const ob_float4 *>(red + i * 16 + 4);
+            s += (b[0] + b[1]) + (b[2] + b[3]);
+        }
         v[i] = s;
     }
 }
@@ -147,53 +154,137 @@ __device__ __forceinline__ ob_u32x4 ob_dec_load_w(const uint32_t *w, int N, int 
     return w4;
 }
 
-// dynamic LDS: [nproj * Kpad halves][MT * 8 waves * 16 rows floats][4 reduction slots of 64 floats]
-// KV = ceil(K / 4096): 8-half vectors per thread in the prologue AND 512-weight chunks per wave per
-// tile; MT = max tiles per workgroup; PRO = prologue.  All compile-time so that the in-flight
-// registers are statically indexed and the load phase is straight-line code: every global load of
-// the kernel (weights, prologue vectors, epilogue scales) is issued before the first use of any of
-// them (loads return in order, so one early use would serialise the rest) -- the kernel pays one
-// memory round trip, not one per stage.
-template <int KV, int MT, bool ALIGNED, int PRO>
+// ---------------------------------------------------------------------------------------------
+// Integer sign path (MATH == 1).  Per projection the activation vector a = fp16(x*h) is quantised
+// once per workgroup to fixed point relative to its largest element, q = a * 2^(22 - e)
+// (|q| < 2^23; exact for every element within 12 binades of the maximum, otherwise rounded at
+// 2^-23 of the maximum -- below fp32 accumulation noise), and split into 4 signed int8 digits.
+// The A operand of v_mfma_i32_16x16x64_i8 is then simply  w & (0x01010101 << j)  : byte i of that
+// dword is bit (8i + j) of the packed word times 2^j, i.e. ONE v_and per 4 weights.  The factor
+// 2^j (and the sign of 0x80 for j = 7) is folded into the activation side: element k with bit
+// position j = k % 8 is stored as m' = q * 2^(7-j) (j < 7) or -q (j = 7), so every product is
+// 128 * b * q.  With B = sum over set bits and S = sum over all (an all-ones "row" on the same
+// MFMA path), z = (S - 2B) / (128 * 2^(22-e)) exactly: integer accumulation, no rounding, no
+// dependence on summation order.  The 4 digits of an element sit in one dword [d0 d1 d2 d3]; the
+// MFMA B operand wants 4 consecutive k of ONE digit per dword, so each quad of lanes does a 4x4
+// byte transpose (2 DPP moves + 2 v_perm per dword) before the LDS write.
+//
+// LDS image per projection: [Q = k/32][digit c][32 bytes], the 32 bytes = dwords j = 0..7, dword j
+// = digit c of k = 32Q + 8i + j for i = 0..3.  MFMA step (q, jh) of chunk ch, lane (g, c): 16 bytes
+// at ((ch*16 + g*4 + q) * 4 + (c & 3)) * 32 + jh * 16.  Lanes with c >= 4 replicate digit c & 3
+// (their result columns are simply not used).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ob_quad_transpose(uint32_t w, uint32_t selA, uint32_t selB)
+{
+    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, w, 0x4E, 0xF, 0xF, false);     // lane ^ 2
+    const uint32_t n1 = __builtin_amdgcn_perm(p1, w, selA);
+    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, n1, 0xB1, 0xF, 0xF, false);    // lane ^ 1
+    return __builtin_amdgcn_perm(p2, n1, selB);
+}
+
+template <int NV, int NW>
+__device__ __forceinline__ void ob_block_max_n(float (&v)[NV], float *red)
+{
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ob_wave_max(v[i]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[i * 16 + wave] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16);
+        float s = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        if (NW > 4) {
+            const ob_float4 b = *reinterpret_cast<const ob_float4 *>(red + i * 16 + 4);
+            s = fmaxf(s, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+        }
+        v[i] = s;
+    }
+}
+
+// 8 MFMAs for one 512-weight chunk of a 16-row tile on the integer path.
+__device__ __forceinline__ void ob_dec_chunk_i8(const ob_u32x4 w4, const char *b_base, ob_i32x4 &acc)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t w = w4[q];
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            const ob_i32x4 bv = *reinterpret_cast<const ob_i32x4 *>(b_base + q * 128 + jh * 16);
+            ob_i32x4 av;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc, 0, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused decode GEMV kernel.
+//   KV      = ceil(K / 4096): 8-half vectors per thread in the prologue AND 512-weight chunks per
+//             wave per tile
+//   MS      = tile slots per projection per workgroup; slot j = (s, p) with p = j % NPROJ the
+//             projection and s = j / NPROJ: the workgroup owns tile s*G + blockIdx.x of projection p.
+//             Projection of a slot is therefore a compile-time constant, and all slots of one
+//             projection share their activation (B operand) reads.
+//   ALIGNED = K % 128 == 0 and 16-byte aligned packed rows
+//   PRO     = prologue, NPROJ = number of projections, MATH: 0 = fp16 MFMA with in-register sign
+//             expansion, 1 = integer path (needs ALIGNED)
+// All compile-time, so the in-flight registers are statically indexed and the load phase is
+// straight-line code: every global load of the kernel (prologue vectors, epilogue scales, weights)
+// is issued before the first use of any of them -- one memory round trip, not one per stage --
+// with the prologue vectors first (loads return in order) so that the prologue runs underneath the
+// weight stream.
+// dynamic LDS: activations (fp16: 2 B/k, i8: 4 digit bytes/k) per projection | cross-wave partials |
+//              reduction slots (256 floats)
+// ---------------------------------------------------------------------------------------------
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
-    // the three projection descriptors live in SGPRs; selection by tile index is scalar arithmetic,
-    // never an indexed read of the kernel-argument segment (that costs a dependent memory round trip)
-    const ObProj P0 = A.p[0], P1 = A.p[1], P2 = A.p[2];
-#define OB_SEL(p, f) ((p) == 0 ? P0.f : ((p) == 1 ? P1.f : P2.f))
+    constexpr int MT = MS * NPROJ;
+    // the projection descriptors live in SGPRs; selection by slot is compile-time
+    const ObProj PP[3] = {A.p[0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;              // launch floor
+#define OB_STAMP(i) do { if (A.dbg && (threadIdx.x & 63) == 0) A.dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define OB_STAMP(i) do { } while (0)
 #endif
+    OB_STAMP(0);
     const int K = A.K;
     const int Kpad = (K + 511) & ~511;
-    const int nproj = A.nproj;
     _Float16 *lds_a = reinterpret_cast<_Float16 *>(smem);
-    float *lds_red = reinterpret_cast<float *>(smem + (size_t)nproj * Kpad * 2);
-    float *red = lds_red + MT * OB_DEC_WAVES * 16;
+    char *lds_q = smem;
+    float *lds_red = reinterpret_cast<float *>(smem + (size_t)NPROJ * Kpad * (MATH == 1 ? 4 : 2));
+    int *lds_redi = reinterpret_cast<int *>(lds_red);   // i8: [MT][8 waves][16 rows][4 digits], S partials [3][8 waves][4 rows][4], S [3][4]
+    constexpr int RED_OFF = MATH == 1 ? (MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) : MT * OB_DEC_WAVES * 16;
+    float *red = lds_red + RED_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gq = lane >> 4;
     const int G = gridDim.x;
-
-    // tiles are numbered projection-major; this workgroup owns tiles b, b + G, b + 2G, ...
-    int tile_base[4];
-    tile_base[0] = 0;
-    tile_base[1] = (P0.N + 15) >> 4;
-    tile_base[2] = tile_base[1] + (nproj > 1 ? (P1.N + 15) >> 4 : 0);
-    tile_base[3] = tile_base[2] + (nproj > 2 ? (P2.N + 15) >> 4 : 0);
-    const int ntiles = tile_base[3];
     const int nchunks = Kpad >> 9;
-    const int my_tiles = (ntiles - 1 - (int)blockIdx.x) / G + 1;               // >= 1 (G <= ntiles)
     const int per_tile = (nchunks - wave + OB_DEC_WAVES - 1) / OB_DEC_WAVES;   // this wave's chunks per tile
 
+    // slot -> tile
+    int trow[MT];
+    bool tval[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int ti = (j / NPROJ) * G + (int)blockIdx.x;
+        const int ntile = (PP[j % NPROJ].N + 15) >> 4;
+        tval[j] = ti < ntile;
+        trow[j] = (tval[j] ? ti : 0) << 4;
+    }
+
     // ---- 1. issue every global load (no use of any loaded value in this section) ----------------
-    // Loads return in order, so the vectors the prologue needs go first and the weight stream last:
-    // the prologue then waits only for its own few KB (vmcnt = number of weight loads still in
-    // flight) and runs underneath the HBM stream.
     // 1a. prologue vectors (raw halves; indices clamped, masked later)
     bool valid[KV];
     int vbase[KV];
-    ob_half8 v0[KV], v1[KV], v2[KV], hp[3][KV];
+    ob_half8 v0[KV], v1[KV], v2[KV], hp[NPROJ][KV];
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
@@ -212,9 +303,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
             v2[v] = *reinterpret_cast<const ob_half8 *>(A.rms_w + vbase[v]);
         }
-        hp[0][v] = *reinterpret_cast<const ob_half8 *>(P0.h + vbase[v]);
-        hp[1][v] = *reinterpret_cast<const ob_half8 *>((nproj > 1 ? P1.h : P0.h) + vbase[v]);
-        hp[2][v] = *reinterpret_cast<const ob_half8 *>((nproj > 2 ? P2.h : P0.h) + vbase[v]);
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) hp[p][v] = *reinterpret_cast<const ob_half8 *>(PP[p].h + vbase[v]);
     }
     if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
     if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
@@ -224,32 +314,41 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
         for (int v = 0; v < KV; ++v) v1[v] = *reinterpret_cast<const ob_half8 *>(row + vbase[v]);
     }
-    // 1c. epilogue scale g of the output row this thread will finalise (clamped, raw)
-    const bool fin = tid < my_tiles * 16;
-    const int t_out = blockIdx.x + (fin ? (tid >> 4) : 0) * G;
-    const int p_out = t_out >= tile_base[2] ? 2 : (t_out >= tile_base[1] ? 1 : 0);
-    const int n_raw = ((t_out - tile_base[p_out]) << 4) + (tid & 15);
-    const int N_out = OB_SEL(p_out, N);
-    const int n_out = min(n_raw, N_out - 1);
-    const _Float16 g_h = OB_SEL(p_out, g)[n_out];
-    _Float16 *u_out = OB_SEL(p_out, u);
+    // 1c. epilogue scale g of the output row this thread will finalise: thread (slot j, row r)
+    const int jo = min(tid >> 4, MT - 1);
+    bool fin = false;
+    int n_out = 0;
+    _Float16 g_h = (_Float16)0;
+    _Float16 *u_out = nullptr;
+    int p_out = 0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        if (j == jo) {
+            const int p = j % NPROJ;
+            const int n_raw = trow[j] + (tid & 15);
+            fin = (tid < MT * 16) && tval[j] && n_raw < PP[p].N;
+            n_out = min(n_raw, PP[p].N - 1);
+            g_h = PP[p].g[n_out];
+            u_out = PP[p].u;
+            p_out = p;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    // 1d. packed weights: items (tile j, chunk wave + 8*ci); out-of-range items re-read a valid one
+    // 1d. packed weights: items (slot j, chunk wave + 8*ci); out-of-range items re-read a valid one
     ob_u32x4 wreg[MT][KV];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int t = blockIdx.x + min(j, my_tiles - 1) * G;
-        const int p = t >= tile_base[2] ? 2 : (t >= tile_base[1] ? 1 : 0);
+        const int p = j % NPROJ;
 #pragma unroll
         for (int ci = 0; ci < KV; ++ci) {
 #ifdef OB_PROFILE_ABLATE
             if (A.ablate == 2 || A.ablate == 3) { wreg[j][ci] = (ob_u32x4){0x12345678u + lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x55aa55aau}; continue; }
 #endif
-            wreg[j][ci] = ob_dec_load_w<ALIGNED>(OB_SEL(p, w), OB_SEL(p, N), K, OB_SEL(p, ldw), (t - tile_base[p]) << 4,
-                                                 min(wave + ci * OB_DEC_WAVES, nchunks - 1), lane);
+            wreg[j][ci] = ob_dec_load_w<ALIGNED>(PP[p].w, PP[p].N, K, PP[p].ldw, trow[j], min(wave + ci * OB_DEC_WAVES, nchunks - 1), lane);
         }
     }
     __builtin_amdgcn_sched_barrier(0);      // nothing above may sink below, no use may rise above
+    OB_STAMP(1);
 
     // ---- 2. prologue arithmetic in the reference's op order; fp16 tensor ops are native packed
     //         fp16 instructions (contraction off: every op rounds once, as torch does) -------------
@@ -270,7 +369,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-        ob_block_sum_n<4>(s, red);
+        ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
         float mg, rg, mu, ru;
         ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
         ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
@@ -281,7 +380,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             for (int i = 0; i < 8; ++i) {
                 const float gate = (float)(_Float16)(((float)v0[v][i] - mg) * rg);      // LayerNorm(gate) -> fp16
                 up[i] = (_Float16)(((float)v1[v][i] - mu) * ru);                        // LayerNorm(up)   -> fp16
-                sg[i] = (_Float16)(gate / (1.0f + __expf(-gate)));                      // silu            -> fp16
+                sg[i] = (_Float16)(gate * __frcp_rn(1.0f + __expf(-gate)));             // silu            -> fp16
             }
             xh[v] = sg * up;                                    // act_fn(gate) * up, modeling_bitllama.py:257
         }
@@ -297,7 +396,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                     for (int i = 0; i < 8; ++i) { const float d = (float)v0[v][i] - c0; s[0] += d; s[1] = fmaf(d, d, s[1]); }
                 }
             }
-            ob_block_sum_n<2>(s, red);
+            ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
             float mean, rstd;
             ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
 #pragma unroll
@@ -323,7 +422,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-        ob_block_sum_n<1>(ss, red + 64);
+        ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 64);
         const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
@@ -335,10 +434,12 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 *reinterpret_cast<ob_half8 *>(A.hres_out + vbase[v]) = hv[v];
         }
     }
-    // a_p = fp16(x * h_p)  (bitnet.py:113), zero padding up to Kpad
+    OB_STAMP(2);
+
+    if (MATH == 0) {
+        // a_p = fp16(x * h_p)  (bitnet.py:113), zero padding up to Kpad
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        if (p < nproj) {
+        for (int p = 0; p < NPROJ; ++p) {
             _Float16 *dst = lds_a + (size_t)p * Kpad;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
@@ -350,49 +451,183 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        OB_STAMP(4);
 
-    // ---- 3. MFMA ---------------------------------------------------------------------------------
-    ob_float4 acc[MT];
+        // ---- 3. MFMA ---------------------------------------------------------------------------
+        ob_float4 acc[MT];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        acc[j] = (ob_float4){0.f, 0.f, 0.f, 0.f};
-        const int t = blockIdx.x + j * G;
-        const int p = t >= tile_base[2] ? 2 : (t >= tile_base[1] ? 1 : 0);
-        const _Float16 *ap = lds_a + (size_t)p * Kpad;
+        for (int j = 0; j < MT; ++j) {
+            acc[j] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+            const _Float16 *ap = lds_a + (size_t)(j % NPROJ) * Kpad;
 #pragma unroll
-        for (int ci = 0; ci < KV; ++ci) {
-            if (j < my_tiles && ci < per_tile) {
+            for (int ci = 0; ci < KV; ++ci) {
+                if (tval[j] && ci < per_tile) {
 #ifdef OB_PROFILE_ABLATE
-                if (A.ablate == 1 || A.ablate == 3) {     // no MFMA / expansion: keep the loaded words alive
-                    acc[j][0] += __uint_as_float((wreg[j][ci][0] ^ wreg[j][ci][1] ^ wreg[j][ci][2] ^ wreg[j][ci][3]) & 0x3fffffffu);
-                    continue;
-                }
+                    if (A.ablate == 1 || A.ablate == 3) {
+                        acc[j][0] += __uint_as_float((wreg[j][ci][0] ^ wreg[j][ci][1] ^ wreg[j][ci][2] ^ wreg[j][ci][3]) & 0x3fffffffu);
+                        continue;
+                    }
 #endif
-                ob_dec_chunk(wreg[j][ci], ap + (size_t)(wave + ci * OB_DEC_WAVES) * 512, gq, acc[j]);
+                    ob_dec_chunk(wreg[j][ci], ap + (size_t)(wave + ci * OB_DEC_WAVES) * 512, gq, acc[j]);
+                }
             }
         }
-    }
-
-    // ---- 4. cross-wave reduction: column 0 of the result (lanes 0,16,32,48 hold rows 4*gq..4*gq+3)
+        OB_STAMP(5);
+        // ---- 4. cross-wave reduction: column 0 (lanes 0,16,32,48 hold rows 4*gq..4*gq+3)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        if (j < my_tiles && (lane & 15) == 0) {
-            float *dst = lds_red + ((j * OB_DEC_WAVES + wave) << 4) + 4 * gq;
-            dst[0] = acc[j][0]; dst[1] = acc[j][1]; dst[2] = acc[j][2]; dst[3] = acc[j][3];
+        for (int j = 0; j < MT; ++j) {
+            if ((lane & 15) == 0) {
+                float *dst = lds_red + ((j * OB_DEC_WAVES + wave) << 4) + 4 * gq;
+                dst[0] = acc[j][0]; dst[1] = acc[j][1]; dst[2] = acc[j][2]; dst[3] = acc[j][3];
+            }
         }
-    }
-    __syncthreads();
-    if (fin && n_raw < N_out) {
-        const int j = tid >> 4, r = tid & 15;
-        float z = 0.f;
+        __syncthreads();
+        if (fin) {
+            const int r = tid & 15;
+            float z = 0.f;
 #pragma unroll
-        for (int w = 0; w < OB_DEC_WAVES; ++w) z += lds_red[((j * OB_DEC_WAVES + w) << 4) + r];
-        // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
-        u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);
+            for (int w = 0; w < OB_DEC_WAVES; ++w) z += lds_red[((jo * OB_DEC_WAVES + w) << 4) + r];
+            // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
+            u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);
+        }
+        OB_STAMP(7);
+    } else {
+        // ---- integer path ----------------------------------------------------------------------
+        // 2b. a_p = fp16(x * h_p), per-projection maximum, fixed-point digits, quad transpose, LDS
+        ob_half8 ah[NPROJ][KV];
+        float amax[NPROJ];
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) {
+            amax[p] = 0.f;
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                ah[p][v] = xh[v] * hp[p][v];
+                if (!valid[v]) ah[p][v] = (ob_half8)(_Float16)0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) amax[p] = fmaxf(amax[p], fabsf((float)ah[p][v][i]));
+            }
+        }
+#ifdef OB_PROFILE_ABLATE
+        if (A.ablate != 5)
+#endif
+        ob_block_max_n<NPROJ, OB_DEC_WAVES>(amax, red + 128);
+        OB_STAMP(3);
+        const uint32_t selA = (lane & 2) ? 0x03020706u : 0x05040100u;
+        const uint32_t selB = (lane & 1) ? 0x03070105u : 0x06020400u;
+        float inv_scale[NPROJ];
+        int sdig[NPROJ];
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) {
+            const int e = amax[p] > 0.f ? (int)((__float_as_uint(amax[p]) >> 23) & 0xffu) - 127 : 0;
+            const float scale = __uint_as_float((uint32_t)(22 - e + 127) << 23);          // 2^(22-e)
+            inv_scale[p] = __uint_as_float((uint32_t)(e - 29 + 127) << 23);               // 2^-(22-e+7)
+            sdig[p] = 0;
+            char *dst = lds_q + (size_t)p * Kpad * 4;
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                const int base = (v * OB_DEC_THREADS + tid) * 8;
+                uint32_t X[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float cj = i < 7 ? (float)(128 >> i) : -1.0f;
+                    const int m = __float2int_rn((float)ah[p][v][i] * (scale * cj));
+                    const uint32_t wd = ((uint32_t)m + 0x00808080u) ^ 0x00808080u;   // 4 signed digits
+                    X[i] = ob_quad_transpose(wd, selA, selB);
+                }
+                if (base < Kpad) {
+                    char *q = dst + (size_t)(base >> 5) * 128 + (lane & 3) * 32;     // Q = base / 32
+                    *reinterpret_cast<ob_u32x4 *>(q) = (ob_u32x4){X[0], X[1], X[2], X[3]};
+                    *reinterpret_cast<ob_u32x4 *>(q + 16) = (ob_u32x4){X[4], X[5], X[6], X[7]};
+                }
+                // S: this lane's digit (lane & 3) of sum_k v_j * m'_k, v_j = 2^j (j < 7), -128 (j = 7)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    sdig[p] = __builtin_amdgcn_sdot4((int)X[i], (int)(0x01010101u << i), sdig[p], false);
+            }
+        }
+        // per-wave digit sums: lanes with equal (lane & 3) inside each 16-lane row, then the 4 rows
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) {
+            int v = sdig[p];
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8 -> lanes 12..15 hold the row sums
+            if ((lane & 15) >= 12) lds_redi[MT * OB_DEC_WAVES * 64 + (((p * OB_DEC_WAVES + wave) * 4 + (lane >> 4)) << 2) + (lane & 3)] = v;
+        }
+        __syncthreads();
+        OB_STAMP(4);
+
+        // 3. MFMA: for every (chunk, word q, half jh): ONE activation read per projection, then one
+        //    MFMA per slot back to back -- consecutive instructions hit different accumulators, so
+        //    the matrix pipe never waits on itself.  Invalid slots run on zero weights.
+        const int cpc = lane & 3;
+        ob_i32x4 acc[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[j] = (ob_i32x4){0, 0, 0, 0};
+        const char *bq = lds_q + (size_t)(gq * 16 + cpc) * 32;
+#pragma unroll
+        for (int ci = 0; ci < KV; ++ci) {
+            if (ci < per_tile) {
+                const int ch = wave + ci * OB_DEC_WAVES;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) {
+                        ob_i32x4 bv[NPROJ];
+#pragma unroll
+                        for (int p = 0; p < NPROJ; ++p)
+                            bv[p] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + q * 128 + jh * 16);
+#pragma unroll
+                        for (int j = 0; j < MT; ++j) {
+                            const uint32_t w = tval[j] ? wreg[j][ci][q] : 0u;
+                            ob_i32x4 av;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
+                            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[j % NPROJ], acc[j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // S of each projection: 8 waves x 4 rows of per-digit partials -> threads 0..4*NPROJ-1 finish them
+        if (tid < 4 * NPROJ) {
+            const int p = tid >> 2, c = tid & 3;
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < OB_DEC_WAVES * 4; ++i) sum += lds_redi[MT * OB_DEC_WAVES * 64 + ((p * OB_DEC_WAVES * 4 + i) << 2) + c];
+            lds_redi[MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + tid] = sum;
+        }
+        OB_STAMP(5);
+        // 4. cross-wave reduction (int32, exact): lanes with column c < 4 hold digit c of rows 4*gq..4*gq+3
+        if ((lane & 15) < 4) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                int *dst = lds_redi + (((j * OB_DEC_WAVES + wave) * 16 + 4 * gq) << 2) + (lane & 15);
+                dst[0] = acc[j][0]; dst[4] = acc[j][1]; dst[8] = acc[j][2]; dst[12] = acc[j][3];
+            }
+        }
+        __syncthreads();
+        if (fin) {
+            const int r = tid & 15;
+            long long Bsum = 0, Ssum = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int bc = 0;
+#pragma unroll
+                for (int w = 0; w < OB_DEC_WAVES; ++w) bc += lds_redi[(((jo * OB_DEC_WAVES + w) * 16 + r) << 2) + c];
+                const int sc = lds_redi[MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + p_out * 4 + c];
+                Bsum += (long long)bc << (8 * c);
+                Ssum += (long long)sc << (8 * c);
+            }
+            float isc = inv_scale[0];
+#pragma unroll
+            for (int p = 1; p < NPROJ; ++p) if (p_out == p) isc = inv_scale[p];
+            const float z = (float)(Ssum - 2 * Bsum) * isc;           // one fp32 rounding of the exact sum
+            u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);    // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
+        }
+        OB_STAMP(7);
     }
-#undef OB_SEL
+#undef OB_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,7 +693,7 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
             s[2] += dk; s[3] += dk * dk; s[4] += dv; s[5] += dv * dv;
         }
     }
-    ob_block_sum_n<6>(s, red);
+    ob_block_sum_n<6, 4>(s, red);
     float mq, rq, mk, rk, mv, rv;
     ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
     ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
@@ -532,7 +767,7 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
         sc[p] = e;
         ls[0] += e;
     }
-    ob_block_sum_n<1>(ls, red + 112);
+    ob_block_sum_n<1, 4>(ls, red + 112);
     const float inv_l = 1.0f / ls[0];
     for (int p = tid; p < L; p += 256) sc[p] = ob_round_h(sc[p] * inv_l);
     __syncthreads();
@@ -603,7 +838,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
                 }
             }
         }
-        ob_block_sum_n<2>(s, red);
+        ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
         float mean, rstd;
         ob_ln_stats(s[0], s[1], c, K, A.ln_eps, mean, rstd);
         float ss[1] = {0.f};
@@ -618,7 +853,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
                 }
             }
         }
-        ob_block_sum_n<1>(ss, red + 32);
+        ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 32);
         const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < OB_DEC_MAXV; ++v) {

@@ -2,6 +2,7 @@
 // allocation, no synchronisation: every call validates its arguments and enqueues kernels on
 // the caller's stream.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -285,27 +286,41 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
-template <int KV, int MT, bool ALIGNED, int PRO>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ>
 static void ob_launch_dec_gemv_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<KV, MT, ALIGNED, PRO>,
+        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MT, ALIGNED, PRO>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
 }
 
-template <int KV, int MT, bool ALIGNED>
-static void ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+// the (prologue, projection count) pairs a decoder layer needs; other pairs are not instantiated
+template <int KV, int MS, bool ALIGNED, int MATH>
+static bool ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
-    switch (a.prologue) {
-    case OB_P_PLAIN: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_PLAIN>(a, G, lds, s); break;
-    case OB_P_EMBED_RMS: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_EMBED_RMS>(a, G, lds, s); break;
-    case OB_P_RES_LN_RMS: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_RES_LN_RMS>(a, G, lds, s); break;
-    default: ob_launch_dec_gemv_t<KV, MT, ALIGNED, OB_P_SWIGLU>(a, G, lds, s); break;
+    if (a.prologue == OB_P_PLAIN && a.nproj == 1) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_PLAIN, MATH, 1>(a, G, lds, s);
+    else if (a.prologue == OB_P_SWIGLU && a.nproj == 1) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_SWIGLU, MATH, 1>(a, G, lds, s);
+    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 2) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_RES_LN_RMS, MATH, 2>(a, G, lds, s);
+    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 3) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_RES_LN_RMS, MATH, 3>(a, G, lds, s);
+    else if (a.prologue == OB_P_EMBED_RMS && a.nproj == 3) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_EMBED_RMS, MATH, 3>(a, G, lds, s);
+    else return false;
+    return true;
+}
+
+// OB_DECODE_MATH=f16 selects the fp16 sign-expansion kernels for A/B measurements; default is the
+// integer path wherever its alignment requirement holds.
+static int ob_decode_math()
+{
+    static int m = -1;
+    if (m < 0) {
+        const char *e = getenv("OB_DECODE_MATH");
+        m = (e && e[0] == 'f') ? 0 : 1;
     }
+    return m;
 }
 
 static int ob_ablate_mode()
@@ -319,12 +334,28 @@ static int ob_ablate_mode()
     return mode;
 }
 
+#ifdef OB_PROFILE_ABLATE
+static unsigned long long *g_dbg = nullptr;
+extern "C" int onebit_debug_read_timing(unsigned long long *host_out, int nblocks)
+{
+    if (!g_dbg) return -1;
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpy(host_out, g_dbg, (size_t)nblocks * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif
+
 static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 {
     ObGemvArgs a = a_in;
     a.ablate = ob_ablate_mode();
-    int ntiles = 0;
-    for (int p = 0; p < a.nproj; ++p) ntiles += (a.p[p].N + 15) / 16;
+#ifdef OB_PROFILE_ABLATE
+    if (getenv("OB_TIMING")) {
+        if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 64 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 64 * sizeof(unsigned long long)); }
+        a.dbg = g_dbg;
+    }
+#endif
+    int max_tiles = 0;
+    for (int p = 0; p < a.nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
     const int Kpad = (a.K + 511) & ~511;
     const int nchunks = Kpad / 512;
     const int kv_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;       // = ceil(K / 4096)
@@ -333,37 +364,40 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
     if (!aligned && KV != 1)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
-    const int mt_max = KV == 1 ? 8 : (KV == 2 ? 4 : 2);
+    // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
+    // one workgroup per CU when a projection has more tiles than that
+    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);
     int G = ob_cu_count();
-    if (ntiles < G) G = ntiles;
-    if ((ntiles + G - 1) / G > mt_max) G = (ntiles + mt_max - 1) / mt_max;
-    const int mt_need = (ntiles + G - 1) / G;
-    // instantiated tile counts: 1 2 3 4 6 8 (KV = 1), 1 2 4 (KV = 2), 1 2 (KV = 4)
-    int MT = mt_need;
-    if (KV == 1) MT = mt_need <= 4 ? mt_need : (mt_need <= 6 ? 6 : 8);
-    else if (KV == 2) MT = mt_need <= 2 ? mt_need : 4;
-    const size_t lds = (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
+    if (max_tiles < G) G = max_tiles;
+    if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
+    const int MS = (max_tiles + G - 1) / G;
+    const int MT = MS * a.nproj;
+    const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
+    const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024;
+    const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
     if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
+    bool ok = false, hit = false;
 #define OB_CASE(P, M)                                                              \
-    if (KV == P && MT == M) {                                                      \
-        ob_launch_dec_gemv_p<P, M, true>(a, G, lds, s);                            \
-        return ob_launch_status("decode gemv");                                    \
+    if (!hit && aligned && KV == P && MS == M) {                                   \
+        hit = true;                                                                \
+        ok = use_i8 ? ob_launch_dec_gemv_p<P, M, true, 1>(a, G, lds, s)            \
+                    : ob_launch_dec_gemv_p<P, M, true, 0>(a, G, lds, s);           \
     }
 #define OB_CASE_U(M)                                                               \
-    if (MT == M) {                                                                 \
-        ob_launch_dec_gemv_p<1, M, false>(a, G, lds, s);                           \
-        return ob_launch_status("decode gemv");                                    \
+    if (!hit && !aligned && MS == M) {                                             \
+        hit = true;                                                                \
+        ok = ob_launch_dec_gemv_p<1, M, false, 0>(a, G, lds, s);                   \
     }
-    if (aligned) {
-        OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 3) OB_CASE(1, 4) OB_CASE(1, 6) OB_CASE(1, 8)
-        OB_CASE(2, 1) OB_CASE(2, 2) OB_CASE(2, 4)
-        OB_CASE(4, 1) OB_CASE(4, 2)
-    } else {
-        OB_CASE_U(1) OB_CASE_U(2) OB_CASE_U(3) OB_CASE_U(4) OB_CASE_U(6) OB_CASE_U(8)
-    }
+    OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 3) OB_CASE(1, 4)
+    OB_CASE(2, 1) OB_CASE(2, 2)
+    OB_CASE(4, 1)
+    OB_CASE_U(1) OB_CASE_U(2) OB_CASE_U(3) OB_CASE_U(4)
 #undef OB_CASE
 #undef OB_CASE_U
-    return ob_fail(ONEBIT_E_SHAPE, "decode gemv: no kernel instance for KV=%d MT=%d", KV, MT);
+    if (!hit) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: no kernel instance for KV=%d MS=%d", KV, MS);
+    if (!ok) return ob_fail(ONEBIT_E_FLAG, "decode gemv: prologue %d with %d projections is not instantiated "
+                            "(PLAIN:1, SWIGLU:1, RES_LN_RMS:2|3, EMBED_RMS:3)", a.prologue, a.nproj);
+    return ob_launch_status("decode gemv");
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,

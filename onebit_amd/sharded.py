@@ -100,8 +100,7 @@ def k_sharded_forward(shard: KShard, x: torch.Tensor, group=None, mode: str = "r
                       eps: float = 1e-5) -> torch.Tensor:
     """x: [T, K] full-width activations (every rank holds them, e.g. the output of the previous
     all-gather) or [T, k1-k0] already sliced.  Returns y [T, N] on every rank."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     T = x.shape[0]
     if x.shape[1] == shard.in_features:
         x_slice = x[:, shard.k0:shard.k1]          # strided view: the kernel takes a row pitch
