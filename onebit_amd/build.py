@@ -32,6 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-ffp-contract=off", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += os.environ.get("OB_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -23,8 +23,10 @@
 #pragma once
 #include "ob_common.h"
 
+#ifndef OB_DEC_THREADS
 #define OB_DEC_THREADS 512
-#define OB_DEC_WAVES 8
+#endif
+#define OB_DEC_WAVES (OB_DEC_THREADS / 64)
 #define OB_DEC_MAXV 4            // per-thread vectors of 8 halves: vector widths up to 16384
 
 struct ObProj {
@@ -73,11 +75,11 @@ __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16);
-        float s = (a[0] + a[1]) + (a[2] + a[3]);
-        if (NW > 4) {
-            const ob_float4 b = *reinterpret_cast<const ob_float4 *>(red + i * 16 + 4);
-            s += (b[0] + b[1]) + (b[2] + b[3]);
+        float s = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < NW; w4 += 4) {
+            const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16 + w4);
+            s += (a[0] + a[1]) + (a[2] + a[3]);
         }
         v[i] = s;
     }
@@ -195,11 +197,11 @@ __device__ __forceinline__ void ob_block_max_n(float (&v)[NV], float *red)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16);
-        float s = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-        if (NW > 4) {
-            const ob_float4 b = *reinterpret_cast<const ob_float4 *>(red + i * 16 + 4);
-            s = fmaxf(s, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+        float s = -INFINITY;
+#pragma unroll
+        for (int w4 = 0; w4 < NW; w4 += 4) {
+            const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16 + w4);
+            s = fmaxf(s, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
         }
         v[i] = s;
     }
@@ -334,19 +336,25 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // 1d. packed weights: items (slot j, chunk wave + 8*ci); out-of-range items re-read a valid one
+    // 1d. packed weights: items (slot j, chunk wave + 8*ci); out-of-range items re-read a valid one.
+    //     Issued in two groups: the first half now, the second half after the first prologue stage,
+    //     so the waves are not parked in a full memory queue while there is VALU work to do and
+    //     the HBM stream runs underneath the prologue.
     ob_u32x4 wreg[MT][KV];
+    constexpr int NITEM = MT * KV, NA = (NITEM + 1) / 2;
+    auto load_items = [&](int first, int last) {
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int p = j % NPROJ;
-#pragma unroll
-        for (int ci = 0; ci < KV; ++ci) {
+        for (int it = 0; it < NITEM; ++it) {
+            if (it >= first && it < last) {
+                const int j = it / KV, ci = it % KV, p = j % NPROJ;
 #ifdef OB_PROFILE_ABLATE
-            if (A.ablate == 2 || A.ablate == 3) { wreg[j][ci] = (ob_u32x4){0x12345678u + lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x55aa55aau}; continue; }
+                if (A.ablate == 2 || A.ablate == 3) { wreg[j][ci] = (ob_u32x4){0x12345678u + lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x55aa55aau}; continue; }
 #endif
-            wreg[j][ci] = ob_dec_load_w<ALIGNED>(PP[p].w, PP[p].N, K, PP[p].ldw, trow[j], min(wave + ci * OB_DEC_WAVES, nchunks - 1), lane);
+                wreg[j][ci] = ob_dec_load_w<ALIGNED>(PP[p].w, PP[p].N, K, PP[p].ldw, trow[j], min(wave + ci * OB_DEC_WAVES, nchunks - 1), lane);
+            }
         }
-    }
+    };
+    load_items(0, NA);
     __builtin_amdgcn_sched_barrier(0);      // nothing above may sink below, no use may rise above
     OB_STAMP(1);
 
@@ -356,6 +364,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     if (PRO == OB_P_PLAIN) {
 #pragma unroll
         for (int v = 0; v < KV; ++v) xh[v] = v0[v];
+        load_items(NA, NITEM);
+        __builtin_amdgcn_sched_barrier(0);
     } else if (PRO == OB_P_SWIGLU) {
         const float c0 = (float)c0h, c1 = (float)c1h;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -370,6 +380,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
+        load_items(NA, NITEM);
+        __builtin_amdgcn_sched_barrier(0);
         float mg, rg, mu, ru;
         ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
         ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
@@ -397,6 +409,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
             ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
+            load_items(NA, NITEM);
+            __builtin_amdgcn_sched_barrier(0);
             float mean, rstd;
             ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
 #pragma unroll
@@ -409,6 +423,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         } else {
 #pragma unroll
             for (int v = 0; v < KV; ++v) hv[v] = v1[v];
+            load_items(NA, NITEM);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // RMSNorm (modeling_bitllama.py:76-81): fp32 variance, x * rsqrt -> fp16, weight * that -> fp16
         float ss[1] = {0.f};
@@ -670,6 +686,15 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
 #pragma unroll
         for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const ob_half8 *>(kr + (i < D8 ? i : 0) * 8);
     }
+    // first 128 cached values: thread (position group pg, 8-dim slice ds) takes positions pg + 16 i
+    const int ds = tid & 15, pg = tid >> 4;
+    ob_half8 vreg[8];
+    {
+        const int dcl = min(8 * ds, D - 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)min(pg + 16 * i, max(pos - 1, 0)) * D + dcl);
+    }
     const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
     const int dq = min(tid, D - 1);
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
@@ -722,35 +747,31 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     }
     __syncthreads();
 
-    // scores: one position per thread; fp32 dot -> fp16 (matmul output) -> / sqrt(D) -> fp16 (:546)
+    // scores: one position per thread; fp32-accumulated dot of fp16 pairs (v_dot2_f32_f16) -> fp16
+    // (matmul output) -> / sqrt(D) -> fp16 (:546)
     const float sqrt_d = sqrtf((float)D);
     float lmax = -INFINITY;
+    auto dot8 = [](const ob_half8 a, const ob_half8 b, float acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const ob_half2 x = {a[2 * e], a[2 * e + 1]}, y = {b[2 * e], b[2 * e + 1]};
+            acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+        }
+        return acc;
+    };
     for (int p = tid; p < L; p += 256) {
         float dot = 0.f;
         if (p == pos) {
-            for (int i = 0; i < D8; ++i) {
-                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(k_s + 8 * i);
-                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kk[e];
-            }
+            for (int i = 0; i < D8; ++i)
+                dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), *reinterpret_cast<const ob_half8 *>(k_s + 8 * i), dot);
         } else if (p < 256) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i < D8) {
-                    const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kreg[i][e];
-                }
-            }
+            for (int i = 0; i < 16; ++i)
+                if (i < D8) dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), kreg[i], dot);
         } else {
             const _Float16 *kr = kbase + (int64_t)p * D;
-            for (int i = 0; i < D8; ++i) {
-                const ob_half8 kk = *reinterpret_cast<const ob_half8 *>(kr + 8 * i);
-                const ob_half8 qq = *reinterpret_cast<const ob_half8 *>(q_s + 8 * i);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dot += (float)qq[e] * (float)kk[e];
-            }
+            for (int i = 0; i < D8; ++i)
+                dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), *reinterpret_cast<const ob_half8 *>(kr + 8 * i), dot);
         }
         const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
         sc[p] = sv;
@@ -772,14 +793,26 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
     for (int p = tid; p < L; p += 256) sc[p] = ob_round_h(sc[p] * inv_l);
     __syncthreads();
 
-    // out = P . V: thread = (position group pg of 16, 8-dim slice ds of 16); 16-byte V loads
-    const int ds = tid & 15, pg = tid >> 4;
+    // out = P . V: thread = (position group pg of 16, 8-dim slice ds of 16); the first 128 positions
+    // come from the registers loaded at kernel entry, later ones by 16-byte loads
     for (int d0 = 0; d0 < D; d0 += 128) {
         const int d = d0 + 8 * ds;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (d < D) {
+            if (d0 == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int p = pg + 16 * i;
+                    if (p < L) {
+                        const float pr = sc[p];
+                        const ob_half8 vv = (p == pos) ? *reinterpret_cast<const ob_half8 *>(v_s + d) : vreg[i];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
+                    }
+                }
+            }
 #pragma unroll 4
-            for (int p = pg; p < L; p += 16) {
+            for (int p = pg + (d0 == 0 ? 128 : 0); p < L; p += 16) {
                 const float pr = sc[p];
                 const ob_half8 vv = (p == pos) ? *reinterpret_cast<const ob_half8 *>(v_s + d)
                                                : *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + d);

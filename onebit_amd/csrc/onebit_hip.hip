@@ -359,14 +359,14 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     const int Kpad = (a.K + 511) & ~511;
     const int nchunks = Kpad / 512;
     const int kv_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;       // = ceil(K / 4096)
-    const int KV = kv_need <= 1 ? 1 : (kv_need <= 2 ? 2 : 4);
+    const int KV = kv_need <= 4 ? kv_need : 4;
     bool aligned = a.K % 128 == 0;
     for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
     if (!aligned && KV != 1)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
     // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
     // one workgroup per CU when a projection has more tiles than that
-    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);
+    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);      // KV 3, 4: one slot
     int G = ob_cu_count();
     if (max_tiles < G) G = max_tiles;
     if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
@@ -390,6 +390,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     }
     OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 3) OB_CASE(1, 4)
     OB_CASE(2, 1) OB_CASE(2, 2)
+    OB_CASE(3, 1)
     OB_CASE(4, 1)
     OB_CASE_U(1) OB_CASE_U(2) OB_CASE_U(3) OB_CASE_U(4)
 #undef OB_CASE
