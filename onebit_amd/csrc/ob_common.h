@@ -52,6 +52,7 @@ __device__ __forceinline__ float ob_block_sum(float v, float *red)
     if ((threadIdx.x & 63) == 0) red[wave] = v;
     __syncthreads();
     float s = 0.f;
+    if (nw == 4) return (red[0] + red[1]) + (red[2] + red[3]);
     for (int i = 0; i < nw; ++i) s += red[i];
     return s;
 }

@@ -176,3 +176,78 @@ __global__ __launch_bounds__(256) void ob_layernorm_kernel(
         y[t * N + n] = (TD)o;
     }
 }
+
+// LayerNorm epilogue v2 for fp16 rows up to 16384 wide with N % 8 == 0: one 256-thread workgroup per
+// token keeps the whole row in registers (8 x 16-byte loads per thread at most) -- one read, exact
+// two-pass statistics (mean, then centred sum of squares), one write.  Same arithmetic as
+// ob_layernorm_kernel; used whenever the shape allows.
+template <bool FROM_Z>
+__global__ __launch_bounds__(256) void ob_layernorm_rows_kernel(
+    const float *z, const _Float16 *uin, const _Float16 *__restrict__ g, const _Float16 *__restrict__ bias,
+    _Float16 *y, _Float16 *uout, int N, float eps, int skip_ln)
+{
+    __shared__ float red[16];
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+    float u[8][8];
+    bool ok[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int base = (v * 256 + tid) * 8;
+        ok[v] = base < N;
+        if (ok[v]) {
+            if (FROM_Z) {
+                const ob_float4 a = *reinterpret_cast<const ob_float4 *>(z + t * N + base);
+                const ob_float4 b = *reinterpret_cast<const ob_float4 *>(z + t * N + base + 4);
+                const ob_half8 gv = *reinterpret_cast<const ob_half8 *>(g + base);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u[v][i] = ob_round_h(ob_round_h(a[i]) * (float)gv[i]);
+                    u[v][i + 4] = ob_round_h(ob_round_h(b[i]) * (float)gv[i + 4]);
+                }
+            } else {
+                const ob_half8 a = *reinterpret_cast<const ob_half8 *>(uin + t * N + base);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) u[v][i] = (float)a[i];
+            }
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (!skip_ln) {
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (ok[v]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += u[v][i];
+            }
+        mean = ob_block_sum(s, red) / (float)N;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (ok[v]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = u[v][i] - mean; q = fmaf(d, d, q); }
+            }
+        const float var = ob_block_sum(q, red + 8) / (float)N;
+        rstd = 1.0f / sqrtf(var + eps);
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int base = (v * 256 + tid) * 8;
+        if (ok[v]) {
+            ob_half8 o, uo;
+            ob_half8 bv = (ob_half8)(_Float16)0;
+            if (bias && !skip_ln) bv = *reinterpret_cast<const ob_half8 *>(bias + base);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uo[i] = (_Float16)u[v][i];
+                float r = skip_ln ? u[v][i] : ob_round_h((u[v][i] - mean) * rstd);
+                if (bias && !skip_ln) r = ob_round_h(r + (float)bv[i]);
+                o[i] = (_Float16)r;
+            }
+            *reinterpret_cast<ob_half8 *>(y + t * N + base) = o;
+            if (uout) *reinterpret_cast<ob_half8 *>(uout + t * N + base) = uo;
+        }
+    }
+}

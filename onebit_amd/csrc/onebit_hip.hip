@@ -142,6 +142,20 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
 #undef OB_MM16
 }
 
+// fp16 LayerNorm epilogue: rows-in-registers kernel when the shape allows, else the generic one
+template <bool FROM_Z>
+static void ob_launch_ln_f16(const float *z, const _Float16 *uin, const _Float16 *g, const _Float16 *bias,
+                             _Float16 *y, _Float16 *uout, int64_t T, int64_t N, float eps, int skip, hipStream_t s)
+{
+    const bool vec = N % 8 == 0 && N <= 16384 && ob_aligned(y, 16) && (!uin || ob_aligned(uin, 16)) &&
+                     (!uout || ob_aligned(uout, 16)) && (!z || ob_aligned(z, 16)) && (!g || ob_aligned(g, 16)) &&
+                     (!bias || ob_aligned(bias, 16));
+    if (vec)
+        hipLaunchKernelGGL((ob_layernorm_rows_kernel<FROM_Z>), dim3((unsigned)T), dim3(256), 0, s, z, uin, g, bias, y, uout, (int)N, eps, skip);
+    else
+        hipLaunchKernelGGL((ob_layernorm_kernel<_Float16, FROM_Z>), dim3((unsigned)T), dim3(256), 0, s, z, uin, g, bias, y, uout, (int)N, eps, skip);
+}
+
 extern "C" size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype)
 {
     if (T <= 0 || N <= 0) return 0;
@@ -177,9 +191,8 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             if (rc) return rc;
         }
         if (skip && ubuf == y) return 0;
-        hipLaunchKernelGGL((ob_layernorm_kernel<_Float16, false>), dim3((unsigned)T), dim3(256), 0, s,
-                           (const float *)nullptr, (const _Float16 *)ubuf, (const _Float16 *)g,
-                           (const _Float16 *)bias, (_Float16 *)y, (_Float16 *)nullptr, (int)N, ln_eps, skip);
+        ob_launch_ln_f16<false>(nullptr, (const _Float16 *)ubuf, (const _Float16 *)g, (const _Float16 *)bias,
+                                (_Float16 *)y, nullptr, T, N, ln_eps, skip, s);
         return ob_launch_status("linear_forward(layernorm)");
     }
     if (dtype == ONEBIT_F16) {
@@ -190,9 +203,8 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
         ob_launch_simple<_Float16>(packed, ldw_bytes, x, K, h, (float *)workspace, T, K, N, s);
         rc = ob_launch_status("linear_forward(simple)");
         if (rc) return rc;
-        hipLaunchKernelGGL((ob_layernorm_kernel<_Float16, true>), dim3((unsigned)T), dim3(256), 0, s,
-                           (const float *)workspace, (const _Float16 *)nullptr, (const _Float16 *)g,
-                           (const _Float16 *)bias, (_Float16 *)y, (_Float16 *)u_or_null, (int)N, ln_eps, skip);
+        ob_launch_ln_f16<true>((const float *)workspace, nullptr, (const _Float16 *)g, (const _Float16 *)bias,
+                               (_Float16 *)y, (_Float16 *)u_or_null, T, N, ln_eps, skip, s);
         return ob_launch_status("linear_forward(layernorm)");
     }
     // F32: z (fp32) staged in y, then g / LayerNorm in place.
@@ -246,9 +258,8 @@ extern "C" int onebit_scale_layernorm(const float *z, const void *g, const void 
     hipStream_t s = (hipStream_t)stream;
     const int skip = (flags & ONEBIT_FLAG_SKIP_LN) ? 1 : 0;
     if (dtype == ONEBIT_F16)
-        hipLaunchKernelGGL((ob_layernorm_kernel<_Float16, true>), dim3((unsigned)T), dim3(256), 0, s, z,
-                           (const _Float16 *)nullptr, (const _Float16 *)g, (const _Float16 *)bias,
-                           (_Float16 *)y, (_Float16 *)u_or_null, (int)N, ln_eps, skip);
+        ob_launch_ln_f16<true>(z, nullptr, (const _Float16 *)g, (const _Float16 *)bias, (_Float16 *)y,
+                               (_Float16 *)u_or_null, T, N, ln_eps, skip, s);
     else
         hipLaunchKernelGGL((ob_layernorm_kernel<float, true>), dim3((unsigned)T), dim3(256), 0, s, z,
                            (const float *)nullptr, (const float *)g, (const float *)bias, (float *)y,

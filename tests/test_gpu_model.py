@@ -47,3 +47,36 @@ def test_eager_model_matches_reference_logits(golden_dir, name):
     for i in range(5):
         if margin[:i + 1].min() > 4.0 * max(ref_gap, 1e-3):
             assert out[0, i] == z["greedy_f16"][0, i], (i, out, z["greedy_f16"])
+
+
+def test_convert_train_checkpoint_and_serve(tmp_path):
+    """Converter step + checkpoint round trip + fused engine: latent weights -> packed inference
+    checkpoint on disk (reference layout) -> load -> logits identical to the in-memory model."""
+    from onebit_amd import checkpoint as C
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=96, hidden_size=128, intermediate_size=384, num_hidden_layers=2,
+                            num_attention_heads=2, max_position_embeddings=64)
+    sd = synthetic_state_dict(cfg, seed=11)
+    g = torch.Generator().manual_seed(3)
+    train_sd = {}
+    for k, v in sd.items():                      # fabricate latent weights whose signs are the packed bits
+        if v.dtype == torch.int8:
+            bits = (v.view(torch.uint8)[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1
+            signs = (1.0 - 2.0 * bits.reshape(v.shape[0], -1).float())
+            train_sd[k] = signs * (0.01 + torch.rand(signs.shape, generator=g))
+        else:
+            train_sd[k] = v
+    conv = C.convert_train_state_dict(train_sd, device=dev)
+    for k, v in sd.items():
+        assert torch.equal(conv[k].cpu(), v), k
+    model = OneBitLlamaForCausalLM(cfg, torch.float16)
+    model.load_state_dict(conv)
+    C.save_inference_checkpoint(model, str(tmp_path))
+    served = C.load_inference_checkpoint(str(tmp_path), device=dev)
+    ids = torch.tensor([[5, 9, 2, 77]], device=dev)
+    ref = model.to(dev).eval()(ids)
+    assert torch.equal(served(ids), ref)
+    out = DecodeEngine(served, max_len=32).generate(ids, max_new_tokens=4)
+    assert out.shape == (1, 8)
