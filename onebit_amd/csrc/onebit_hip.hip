@@ -156,6 +156,11 @@ static void ob_launch_ln_f16(const float *z, const _Float16 *uin, const _Float16
         hipLaunchKernelGGL((ob_layernorm_kernel<_Float16, FROM_Z>), dim3((unsigned)T), dim3(256), 0, s, z, uin, g, bias, y, uout, (int)N, eps, skip);
 }
 
+struct ObGemvArgs;
+static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s);
+static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const void *x, const void *h, const void *g,
+                                void *u, int64_t K, int64_t N, hipStream_t s);
+
 extern "C" size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype)
 {
     if (T <= 0 || N <= 0) return 0;
@@ -185,6 +190,10 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
         _Float16 *ubuf = (_Float16 *)(u_or_null ? u_or_null : y);
         if (K == 0) {
             (void)hipMemsetAsync(ubuf, 0, (size_t)T * N * 2, s);
+        } else if (T == 1 && K % 128 == 0 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && K <= 16384) {
+            // one token: the persistent decode GEMV (plain prologue) instead of the 16-token tile kernel
+            rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
+            if (rc) return rc;
         } else {
             ob_launch_mm16<false>(packed, ldw_bytes, x, K, h, g, ubuf, nullptr, T, K, N, s);
             rc = ob_launch_status("linear_forward(mm16)");
@@ -384,7 +393,8 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     const int MS = (max_tiles + G - 1) / G;
     const int MT = MS * a.nproj;
     const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
-    const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024;
+    // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
+    const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2);
     const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
     if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
     bool ok = false, hit = false;
@@ -410,6 +420,18 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     if (!ok) return ob_fail(ONEBIT_E_FLAG, "decode gemv: prologue %d with %d projections is not instantiated "
                             "(PLAIN:1, SWIGLU:1, RES_LN_RMS:2|3, EMBED_RMS:3)", a.prologue, a.nproj);
     return ob_launch_status("decode gemv");
+}
+
+static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const void *x, const void *h, const void *g,
+                                void *u, int64_t K, int64_t N, hipStream_t s)
+{
+    ObGemvArgs a = {};
+    a.nproj = 1; a.K = (int)K; a.prologue = OB_P_PLAIN;
+    a.p[0].w = (const uint32_t *)packed; a.p[0].h = (const _Float16 *)h; a.p[0].g = (const _Float16 *)g;
+    a.p[0].u = (_Float16 *)u; a.p[0].N = (int)N; a.p[0].K = (int)K; a.p[0].ldw = (int)(ldw_bytes / 4);
+    a.xin = (const _Float16 *)x;
+    a.rms_eps = 1e-6f; a.ln_eps = 1e-5f;
+    return ob_launch_dec_gemv(a, s);
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
