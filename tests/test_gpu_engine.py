@@ -179,3 +179,39 @@ def test_fused_gemv_each_prologue(H, I):
     od = torch.empty(H, device=dev, dtype=f16)
     fused_gemv([mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu)
     check(od, _ref_u(mlp.down_proj, act), "swiglu")
+
+
+@pytest.mark.parametrize("cfgkw,prompt_len,steps", [
+    # grouped-query attention: 8 query heads share 2 kv heads
+    (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+          num_key_value_heads=2, max_position_embeddings=64), 7, 10),
+    # long context: > 256 cached positions (keys beyond the register-preloaded window, values beyond 128)
+    (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+          max_position_embeddings=512), 300, 6),
+])
+def test_engine_attention_variants(cfgkw, prompt_len, steps):
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(**cfgkw)
+    model = build_synthetic_model(cfg, seed=9, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    ids = torch.randint(0, cfg.vocab_size, (1, prompt_len), generator=g).to(dev)
+    cache = model.new_cache(1, cfg.max_position_embeddings)
+    lg = model(ids, cache)
+    tok = lg[:, -1].argmax(-1, keepdim=True)
+    ref_logits, ref_toks = [], [int(tok)]
+    for _ in range(steps):
+        lg = model(tok, cache)
+        ref_logits.append(lg[0, -1].cpu().numpy())
+        tok = lg[:, -1].argmax(-1, keepdim=True)
+        ref_toks.append(int(tok))
+    eng = DecodeEngine(model, max_len=cfg.max_position_embeddings)
+    eng.prefill(ids)
+    assert eng.first_token == ref_toks[0]
+    ref = np.stack(ref_logits)
+    for i in range(steps):
+        eng.set_state(ref_toks[i], prompt_len + i)
+        eng.step()
+        err = np.abs(eng.logits().cpu().numpy() - ref[i]).max()
+        assert err <= 6e-3 * np.abs(ref).max(), (i, err)
