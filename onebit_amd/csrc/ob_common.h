@@ -43,6 +43,21 @@ __device__ __forceinline__ float ob_wave_max(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+typedef unsigned short ob_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t ob_wave_max_u32(uint32_t v)
+{
+#define OB_DPP_U(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+    v = max(v, OB_DPP_U(v, 0xB1, 0xF));
+    v = max(v, OB_DPP_U(v, 0x4E, 0xF));
+    v = max(v, OB_DPP_U(v, 0x141, 0xF));
+    v = max(v, OB_DPP_U(v, 0x140, 0xF));
+    v = max(v, OB_DPP_U(v, 0x142, 0xA));
+    v = max(v, OB_DPP_U(v, 0x143, 0xC));
+#undef OB_DPP_U
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Block-wide sum through LDS; `red` holds >= (blockDim.x / 64) floats.  All threads get the result.
 __device__ __forceinline__ float ob_block_sum(float v, float *red)
 {

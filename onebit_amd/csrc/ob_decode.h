@@ -262,7 +262,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     _Float16 *lds_a = reinterpret_cast<_Float16 *>(smem);
     char *lds_q = smem;
     float *lds_red = reinterpret_cast<float *>(smem + (size_t)NPROJ * Kpad * (MATH == 1 ? 4 : 2));
-    int *lds_redi = reinterpret_cast<int *>(lds_red);   // i8: [MT][8 waves][16 rows][4 digits], S partials [3][8 waves][4 rows][4], S [3][4]
+    // i8: lds_red holds [MT][8 waves][16 rows][4 digits] scaled fp32 partials
     constexpr int RED_OFF = MATH == 1 ? (MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) : MT * OB_DEC_WAVES * 16;
     float *red = lds_red + RED_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -467,7 +467,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-        __syncthreads();
+        // no barrier: chunk (wave + 8*ci) is exactly the elements this wave's lanes hold for vector
+        // ci, so every wave reads back only what it wrote itself (LDS ops of one wave are in order)
         OB_STAMP(4);
 
         // ---- 3. MFMA ---------------------------------------------------------------------------
@@ -510,24 +511,28 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         OB_STAMP(7);
     } else {
         // ---- integer path ----------------------------------------------------------------------
-        // 2b. a_p = fp16(x * h_p), per-projection maximum, fixed-point digits, quad transpose, LDS
+        // 2b. a_p = fp16(x * h_p); everything from here to the MFMAs is wave-local: chunk
+        //     (wave + 8*ci) is exactly the elements this wave's lanes hold for vector ci, so each wave
+        //     quantises its own elements relative to ITS largest one (exponent e per wave and
+        //     projection), writes the digits, reads them back and multiplies -- no workgroup barrier,
+        //     and one wave's VALU work overlaps another wave's MFMAs on the same SIMD.
         ob_half8 ah[NPROJ][KV];
-        float amax[NPROJ];
+        int e_w[NPROJ];
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
-            amax[p] = 0.f;
+            ob_u16x2 mx = {0, 0};
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
                 ah[p][v] = xh[v] * hp[p][v];
                 if (!valid[v]) ah[p][v] = (ob_half8)(_Float16)0;
+                const ob_u32x4 bits = __builtin_bit_cast(ob_u32x4, ah[p][v]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) amax[p] = fmaxf(amax[p], fabsf((float)ah[p][v][i]));
+                for (int d = 0; d < 4; ++d)             // |a| as fp16 bit patterns order like unsigned integers
+                    mx = __builtin_elementwise_max(mx, __builtin_bit_cast(ob_u16x2, bits[d] & 0x7fff7fffu));
             }
+            const uint32_t m = ob_wave_max_u32(max((uint32_t)mx[0], (uint32_t)mx[1]));
+            e_w[p] = (int)max(m >> 10, 1u) - 15;        // |a| < 2^(e+1) for every element of this wave
         }
-#ifdef OB_PROFILE_ABLATE
-        if (A.ablate != 5)
-#endif
-        ob_block_max_n<NPROJ, OB_DEC_WAVES>(amax, red + 128);
         OB_STAMP(3);
         const uint32_t selA = (lane & 2) ? 0x03020706u : 0x05040100u;
         const uint32_t selB = (lane & 1) ? 0x03070105u : 0x06020400u;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         int sdig[NPROJ];
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
-            const int e = amax[p] > 0.f ? (int)((__float_as_uint(amax[p]) >> 23) & 0xffu) - 127 : 0;
+            const int e = e_w[p];
             const float scale = __uint_as_float((uint32_t)(22 - e + 127) << 23);          // 2^(22-e)
             inv_scale[p] = __uint_as_float((uint32_t)(e - 29 + 127) << 23);               // 2^-(22-e+7)
             sdig[p] = 0;
@@ -562,15 +567,18 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                     sdig[p] = __builtin_amdgcn_sdot4((int)X[i], (int)(0x01010101u << i), sdig[p], false);
             }
         }
-        // per-wave digit sums: lanes with equal (lane & 3) inside each 16-lane row, then the 4 rows
+        // S of this wave per digit, exact, in every lane with that (lane & 3): rotate-add inside the
+        // 16-lane rows, then the two gfx950 row swaps
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
             int v = sdig[p];
-            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
-            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8 -> lanes 12..15 hold the row sums
-            if ((lane & 15) >= 12) lds_redi[MT * OB_DEC_WAVES * 64 + (((p * OB_DEC_WAVES + wave) * 4 + (lane >> 4)) << 2) + (lane & 3)] = v;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);     // row_ror:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);     // row_ror:8
+            auto s16 = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
+            v = (int)(s16[0] + s16[1]);
+            auto s32 = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)v, false, false);
+            sdig[p] = (int)(s32[0] + s32[1]);
         }
-        __syncthreads();
         OB_STAMP(4);
 
         // 3. MFMA: for every (chunk, word q, half jh): ONE activation read per projection, then one
@@ -605,40 +613,29 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-        // S of each projection: 8 waves x 4 rows of per-digit partials -> threads 0..4*NPROJ-1 finish them
-        if (tid < 4 * NPROJ) {
-            const int p = tid >> 2, c = tid & 3;
-            int sum = 0;
-#pragma unroll
-            for (int i = 0; i < OB_DEC_WAVES * 4; ++i) sum += lds_redi[MT * OB_DEC_WAVES * 64 + ((p * OB_DEC_WAVES * 4 + i) << 2) + c];
-            lds_redi[MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + tid] = sum;
-        }
         OB_STAMP(5);
-        // 4. cross-wave reduction (int32, exact): lanes with column c < 4 hold digit c of rows 4*gq..4*gq+3
+        // 4. per wave, row and digit c: (S_c - 2 B_c) is exact in int32; one conversion to fp32, scaled
+        //    by 2^(8c) / (128 * 2^(22-e)) (powers of two: exact), then a fixed-order fp32 sum over the
+        //    4 digits and 8 waves in the finishing thread -- deterministic, error <= a few 2^-24
         if ((lane & 15) < 4) {
+            const float dscale = __uint_as_float((uint32_t)(127 + 8 * (lane & 3)) << 23);
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                int *dst = lds_redi + (((j * OB_DEC_WAVES + wave) * 16 + 4 * gq) << 2) + (lane & 15);
-                dst[0] = acc[j][0]; dst[4] = acc[j][1]; dst[8] = acc[j][2]; dst[12] = acc[j][3];
+                const float f = dscale * inv_scale[j % NPROJ];
+                float *dst = lds_red + (((j * OB_DEC_WAVES + wave) * 16 + 4 * gq) << 2) + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[4 * r] = (float)(sdig[j % NPROJ] - 2 * acc[j][r]) * f;
             }
         }
         __syncthreads();
         if (fin) {
             const int r = tid & 15;
-            long long Bsum = 0, Ssum = 0;
+            float z = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int bc = 0;
-#pragma unroll
-                for (int w = 0; w < OB_DEC_WAVES; ++w) bc += lds_redi[(((jo * OB_DEC_WAVES + w) * 16 + r) << 2) + c];
-                const int sc = lds_redi[MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + p_out * 4 + c];
-                Bsum += (long long)bc << (8 * c);
-                Ssum += (long long)sc << (8 * c);
+            for (int w = 0; w < OB_DEC_WAVES; ++w) {
+                const ob_float4 t = *reinterpret_cast<const ob_float4 *>(lds_red + (((jo * OB_DEC_WAVES + w) * 16 + r) << 2));
+                z += (t[0] + t[1]) + (t[2] + t[3]);
             }
-            float isc = inv_scale[0];
-#pragma unroll
-            for (int p = 1; p < NPROJ; ++p) if (p_out == p) isc = inv_scale[p];
-            const float z = (float)(Ssum - 2 * Bsum) * isc;           // one fp32 rounding of the exact sum
             u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);    // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
         }
         OB_STAMP(7);

@@ -45,4 +45,4 @@ for kind in ("o", "qkv", "gateup", "down"):
             lo += np.nanmin(st, axis=0) - base; hi += np.nanmax(st, axis=0) - base; n += 1
     lo /= n; hi /= n
     print(os.environ.get("OB_DECODE_MATH", "i8"), kind.ljust(7), "cycles since first wave entry, earliest..latest wave:",
-          "  ".join("%s %d..%d" % (nm, a, b) for nm, a, b in zip(["entry"] + names, lo, hi)))
+          "  ".join("%s %d..%d" % (nm, a, b) for nm, a, b in zip(["entry"] + names, np.nan_to_num(lo, nan=-1), np.nan_to_num(hi, nan=-1))))
