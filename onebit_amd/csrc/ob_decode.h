@@ -224,6 +224,28 @@ __device__ __forceinline__ void ob_dec_chunk_i8(const ob_u32x4 w4, const char *b
     }
 }
 
+// Element ownership in the GEMV prologue.  Contiguous (fp16 path): the thread holds 8 consecutive
+// elements.  Strided (integer path): lane (Q = lane >> 2, jp = lane & 3) of the wave that owns a
+// 512-element chunk holds elements 32Q + 8i + 2jp + s (i = 0..3, s = 0..1; vector index 2i + s), i.e.
+// for each of its two bit positions j = 2jp + s the four elements whose sign bits are the four BYTES
+// of one masked weight word -- so the digit-planar MFMA operand is a thread-local 4x4 byte transpose.
+template <bool STRIDED>
+__device__ __forceinline__ ob_half8 ob_ld8(const _Float16 *p)
+{
+    if (!STRIDED) return *reinterpret_cast<const ob_half8 *>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    const ob_u32x4 r = {q[0], q[4], q[8], q[12]};
+    return __builtin_bit_cast(ob_half8, r);
+}
+template <bool STRIDED>
+__device__ __forceinline__ void ob_st8(_Float16 *p, const ob_half8 v)
+{
+    if (!STRIDED) { *reinterpret_cast<ob_half8 *>(p) = v; return; }
+    uint32_t *q = reinterpret_cast<uint32_t *>(p);
+    const ob_u32x4 r = __builtin_bit_cast(ob_u32x4, v);
+    q[0] = r[0]; q[4] = r[1]; q[8] = r[2]; q[12] = r[3];
+}
+
 // ---------------------------------------------------------------------------------------------
 // The fused decode GEMV kernel.
 //   KV      = ceil(K / 4096): 8-half vectors per thread in the prologue AND 512-weight chunks per
@@ -247,6 +269,7 @@ template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
     constexpr int MT = MS * NPROJ;
+    constexpr bool SD = MATH == 1;          // strided element ownership (see ob_ld8)
     // the projection descriptors live in SGPRs; selection by slot is compile-time
     const ObProj PP[3] = {A.p[0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,23 +313,24 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
-        const int base = (v * OB_DEC_THREADS + tid) * 8;
-        valid[v] = base < K;
-        vbase[v] = valid[v] ? base : 0;
+        const int base = SD ? (v * OB_DEC_WAVES + wave) * 512 + (lane >> 2) * 32 + (lane & 3) * 2
+                            : (v * OB_DEC_THREADS + tid) * 8;
+        valid[v] = base < K;                    // K % 32 == 0: a thread's 8 elements are all in or all out
+        vbase[v] = valid[v] ? base : (SD ? (lane & 3) * 2 : 0);
         if (PRO == OB_P_PLAIN) {
-            v0[v] = *reinterpret_cast<const ob_half8 *>(A.xin + vbase[v]);
+            v0[v] = ob_ld8<SD>(A.xin + vbase[v]);
         } else if (PRO == OB_P_SWIGLU) {
-            v0[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + vbase[v]);
-            v1[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + vbase[v]);
+            v0[v] = ob_ld8<SD>(A.u_gate + vbase[v]);
+            v1[v] = ob_ld8<SD>(A.u_up + vbase[v]);
         } else {
             if (PRO == OB_P_RES_LN_RMS) {
-                v0[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + vbase[v]);
-                v1[v] = *reinterpret_cast<const ob_half8 *>(A.hres_in + vbase[v]);
+                v0[v] = ob_ld8<SD>(A.u_prev + vbase[v]);
+                v1[v] = ob_ld8<SD>(A.hres_in + vbase[v]);
             }
-            v2[v] = *reinterpret_cast<const ob_half8 *>(A.rms_w + vbase[v]);
+            v2[v] = ob_ld8<SD>(A.rms_w + vbase[v]);
         }
 #pragma unroll
-        for (int p = 0; p < NPROJ; ++p) hp[p][v] = *reinterpret_cast<const ob_half8 *>(PP[p].h + vbase[v]);
+        for (int p = 0; p < NPROJ; ++p) hp[p][v] = ob_ld8<SD>(PP[p].h + vbase[v]);
     }
     if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
     if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     if (PRO == OB_P_EMBED_RMS) {
         const _Float16 *row = A.embed + (int64_t)(*A.token) * K;
 #pragma unroll
-        for (int v = 0; v < KV; ++v) v1[v] = *reinterpret_cast<const ob_half8 *>(row + vbase[v]);
+        for (int v = 0; v < KV; ++v) v1[v] = ob_ld8<SD>(row + vbase[v]);
     }
     // 1c. epilogue scale g of the output row this thread will finalise: thread (slot j, row r)
     const int jo = min(tid >> 4, MT - 1);
@@ -446,8 +470,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
             for (int i = 0; i < 8; ++i) t[i] = (_Float16)((float)hv[v][i] * rs);
             xh[v] = v2[v] * t;
-            if (blockIdx.x == 0 && A.hres_out && valid[v])
-                *reinterpret_cast<ob_half8 *>(A.hres_out + vbase[v]) = hv[v];
+            if (blockIdx.x == 0 && A.hres_out && valid[v]) ob_st8<SD>(A.hres_out + vbase[v], hv[v]);
         }
     }
     OB_STAMP(2);
@@ -519,12 +542,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         ob_half8 ah[NPROJ][KV];
         int e_w[NPROJ];
 #pragma unroll
+        for (int v = 0; v < KV; ++v)
+            if (!valid[v]) xh[v] = (ob_half8)(_Float16)0;          // zero padding up to Kpad
+#pragma unroll
         for (int p = 0; p < NPROJ; ++p) {
             ob_u16x2 mx = {0, 0};
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
                 ah[p][v] = xh[v] * hp[p][v];
-                if (!valid[v]) ah[p][v] = (ob_half8)(_Float16)0;
                 const ob_u32x4 bits = __builtin_bit_cast(ob_u32x4, ah[p][v]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d)             // |a| as fp16 bit patterns order like unsigned integers
@@ -534,8 +559,12 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             e_w[p] = (int)max(m >> 10, 1u) - 15;        // |a| < 2^(e+1) for every element of this wave
         }
         OB_STAMP(3);
-        const uint32_t selA = (lane & 2) ? 0x03020706u : 0x05040100u;
-        const uint32_t selB = (lane & 1) ? 0x03070105u : 0x06020400u;
+        // this lane's two bit positions j = 2jp + s: compensation 2^(7-j) (j < 7) or -1 (j = 7) folded
+        // into the quantisation scale, v_j = 2^j / -128 as the byte of the S dot product
+        const int jp = lane & 3;
+        const float cj0 = __uint_as_float((uint32_t)(127 + 7 - 2 * jp) << 23);
+        const float cj1 = jp < 3 ? __uint_as_float((uint32_t)(127 + 6 - 2 * jp) << 23) : -1.0f;
+        const int vj0 = (int)(0x01010101u << (2 * jp)), vj1 = (int)(0x01010101u << (2 * jp + 1));
         float inv_scale[NPROJ];
         int sdig[NPROJ];
 #pragma unroll
@@ -543,40 +572,56 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             const int e = e_w[p];
             const float scale = __uint_as_float((uint32_t)(22 - e + 127) << 23);          // 2^(22-e)
             inv_scale[p] = __uint_as_float((uint32_t)(e - 29 + 127) << 23);               // 2^-(22-e+7)
-            sdig[p] = 0;
-            char *dst = lds_q + (size_t)p * Kpad * 4;
+            const float sc0 = scale * cj0, sc1 = scale * cj1;
+            int D[4] = {0, 0, 0, 0};
+            char *dst = lds_q + (size_t)p * Kpad * 4 + (lane >> 2) * 128 + jp * 8;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
-                const int base = (v * OB_DEC_THREADS + tid) * 8;
-                uint32_t X[8];
+                uint32_t T[2][4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float cj = i < 7 ? (float)(128 >> i) : -1.0f;
-                    const int m = __float2int_rn((float)ah[p][v][i] * (scale * cj));
-                    const uint32_t wd = ((uint32_t)m + 0x00808080u) ^ 0x00808080u;   // 4 signed digits
-                    X[i] = ob_quad_transpose(wd, selA, selB);
-                }
-                if (base < Kpad) {
-                    char *q = dst + (size_t)(base >> 5) * 128 + (lane & 3) * 32;     // Q = base / 32
-                    *reinterpret_cast<ob_u32x4 *>(q) = (ob_u32x4){X[0], X[1], X[2], X[3]};
-                    *reinterpret_cast<ob_u32x4 *>(q + 16) = (ob_u32x4){X[4], X[5], X[6], X[7]};
-                }
-                // S: this lane's digit (lane & 3) of sum_k v_j * m'_k, v_j = 2^j (j < 7), -128 (j = 7)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint32_t W[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    sdig[p] = __builtin_amdgcn_sdot4((int)X[i], (int)(0x01010101u << i), sdig[p], false);
+                    for (int i = 0; i < 4; ++i) {
+                        // fma(a, s, 0) = a * s exactly; written as an fma so that the fp16 -> fp32
+                        // conversion rides in the same instruction (v_fma_mix_f32)
+                        const float f = __builtin_fmaf((float)ah[p][v][2 * i + s2], s2 ? sc1 : sc0, 0.0f);
+                        int m;
+                        asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(m) : "v"(f));      // floor(f + 0.5)
+                        W[i] = ((uint32_t)m + 0x00808080u) ^ 0x00808080u;         // 4 signed digits [d0 d1 d2 d3]
+                    }
+                    // 4x4 byte transpose: T[c] = digit c of elements i = 0..3
+                    const uint32_t u0 = __builtin_amdgcn_perm(W[1], W[0], 0x05010400u), u1 = __builtin_amdgcn_perm(W[1], W[0], 0x07030602u);
+                    const uint32_t w0 = __builtin_amdgcn_perm(W[3], W[2], 0x05010400u), w1 = __builtin_amdgcn_perm(W[3], W[2], 0x07030602u);
+                    T[s2][0] = __builtin_amdgcn_perm(w0, u0, 0x05040100u);
+                    T[s2][1] = __builtin_amdgcn_perm(w0, u0, 0x07060302u);
+                    T[s2][2] = __builtin_amdgcn_perm(w1, u1, 0x05040100u);
+                    T[s2][3] = __builtin_amdgcn_perm(w1, u1, 0x07060302u);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) D[c] = __builtin_amdgcn_sdot4((int)T[s2][c], s2 ? vj1 : vj0, D[c], false);
+                }
+                if ((v * OB_DEC_WAVES + wave) * 512 < Kpad) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<ob_u32x2 *>(dst + (size_t)(v * OB_DEC_WAVES + wave) * 2048 + c * 32) = (ob_u32x2){T[0][c], T[1][c]};
+                }
             }
-        }
-        // S of this wave per digit, exact, in every lane with that (lane & 3): rotate-add inside the
-        // 16-lane rows, then the two gfx950 row swaps
-#pragma unroll
-        for (int p = 0; p < NPROJ; ++p) {
-            int v = sdig[p];
-            v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);     // row_ror:4
-            v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);     // row_ror:8
-            auto s16 = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
-            v = (int)(s16[0] + s16[1]);
-            auto s32 = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)v, false, false);
+            // S of this wave, exact, digit (lane & 3) in every lane: a transposing reduction (4 values
+            // -> 2 -> 1 across lane ^ 2, lane ^ 1), rotate-adds inside the 16-lane rows, then the two
+            // gfx950 row swaps
+            const bool hi2 = lane & 2, hi1 = lane & 1;
+            int k0 = hi2 ? D[2] : D[0], k1 = hi2 ? D[3] : D[1];
+            const int s0 = hi2 ? D[0] : D[2], s1 = hi2 ? D[1] : D[3];
+            k0 += __builtin_amdgcn_update_dpp(0, s0, 0x4E, 0xF, 0xF, false);    // lane ^ 2
+            k1 += __builtin_amdgcn_update_dpp(0, s1, 0x4E, 0xF, 0xF, false);
+            int t = hi1 ? k1 : k0;
+            const int sd = hi1 ? k0 : k1;
+            t += __builtin_amdgcn_update_dpp(0, sd, 0xB1, 0xF, 0xF, false);     // lane ^ 1
+            t += __builtin_amdgcn_update_dpp(0, t, 0x124, 0xF, 0xF, false);     // row_ror:4
+            t += __builtin_amdgcn_update_dpp(0, t, 0x128, 0xF, 0xF, false);     // row_ror:8
+            auto s16 = __builtin_amdgcn_permlane16_swap((uint32_t)t, (uint32_t)t, false, false);
+            t = (int)(s16[0] + s16[1]);
+            auto s32 = __builtin_amdgcn_permlane32_swap((uint32_t)t, (uint32_t)t, false, false);
             sdig[p] = (int)(s32[0] + s32[1]);
         }
         OB_STAMP(4);
