@@ -701,57 +701,83 @@ struct ObAttnArgs {
     float ln_eps;
 };
 
-__global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
+// Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and
+// 8-dim slice ds of the head; a 16-lane DPP row spans the head dimension, so the q.k dots are row
+// reductions and every lane of a row holds its row's scores and probabilities -- no LDS round trip
+// between scores, softmax and P.V.  Five barriers: LayerNorm statistics, q/k/v of the new token,
+// softmax maximum, softmax denominator, output partials.  D <= 128.
+#define OB_ATTN_THREADS 512
+#define OB_ATTN_WAVES (OB_ATTN_THREADS / 64)
+__device__ __forceinline__ float ob_row_sum(float v)     // sum over the 16 lanes of a DPP row, in every lane
+{
+    v += OB_DPP_F(v, 0xB1, 0xF);
+    v += OB_DPP_F(v, 0x4E, 0xF);
+    v += OB_DPP_F(v, 0x141, 0xF);
+    v += OB_DPP_F(v, 0x140, 0xF);
+    return v;
+}
+__device__ __forceinline__ float ob_rows_sum(float v)    // row-uniform values: sum over the wave's 4 rows
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float ob_rows_max(float v)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAttnArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
     const int head = blockIdx.x, kvh = head / (H / Hkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *red = reinterpret_cast<float *>(smem);                    // 2 slots: 6*16 + 16 floats
-    _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);         // [D]
-    _Float16 *k_s = q_s + D;                                         // [D] new key (post RoPE)
-    _Float16 *v_s = k_s + D;                                         // [D] new value
-    _Float16 *tmp = v_s + D;                                         // [2*D] pre-RoPE q, k
-    float *sc = reinterpret_cast<float *>(tmp + 2 * D);              // [max_len] scores / probs
-    float *po = sc + A.max_len;                                      // [16][D] partial outputs
+    float *red = reinterpret_cast<float *>(smem);                    // [0,96) stats, [96,104) max, [112,120) sum
+    _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);         // [128] query (post RoPE), zero padded
+    _Float16 *k_s = q_s + 128;                                       // [128] new key (post RoPE)
+    _Float16 *v_s = k_s + 128;                                       // [128] new value
+    float *po = reinterpret_cast<float *>(v_s + 128);                // [8 waves][128] partial outputs
+    float *sc = po + OB_ATTN_WAVES * 128;                            // [max_len] scores of positions >= 128
 
-    // ---- loads first: position, LayerNorm inputs, rope row, and the first 256 cached keys ------
+    // ---- every load of the short-context path is issued here ------------------------------------
     const int pos = *A.pos;
     const int L = pos + 1;
     const int NQ = H * D, NK = Hkv * D;
     const _Float16 *kbase = A.kcache + (int64_t)kvh * A.max_len * D;
     const _Float16 *vbase = A.vcache + (int64_t)kvh * A.max_len * D;
-    const int D8 = D >> 3;
-    ob_half8 kreg[16];
-    {
-        const _Float16 *kr = kbase + (int64_t)min(tid, max(pos - 1, 0)) * D;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const ob_half8 *>(kr + (i < D8 ? i : 0) * 8);
-    }
-    // first 128 cached values: thread (position group pg, 8-dim slice ds) takes positions pg + 16 i
     const int ds = tid & 15, pg = tid >> 4;
-    ob_half8 vreg[8];
-    {
-        const int dcl = min(8 * ds, D - 8);
+    const bool dok = 8 * ds < D;
+    const int dcl = dok ? 8 * ds : 0;
+    const int plast = max(pos - 1, 0);
+    ob_half8 kreg[4], vreg[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)min(pg + 16 * i, max(pos - 1, 0)) * D + dcl);
+    for (int i = 0; i < 4; ++i) {
+        const int64_t off = (int64_t)min(pg + 32 * i, plast) * D + dcl;
+        kreg[i] = *reinterpret_cast<const ob_half8 *>(kbase + off);
+        vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
     }
     const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
-    const int dq = min(tid, D - 1);
+    const int half = D >> 1;
+    const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
+    const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
     const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
     __builtin_amdgcn_sched_barrier(0);
 
     // LayerNorm statistics of the three rows (each workgroup recomputes them)
     const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int base = tid * 8; base < NQ; base += 256 * 8) {
+    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8) {
         const ob_half8 t = *reinterpret_cast<const ob_half8 *>(A.u_q + base);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float d = (float)t[i] - cq; s[0] += d; s[1] += d * d; }
     }
-    for (int base = tid * 8; base < NK; base += 256 * 8) {
+    for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
         const ob_half8 tk = *reinterpret_cast<const ob_half8 *>(A.u_k + base);
         const ob_half8 tv = *reinterpret_cast<const ob_half8 *>(A.u_v + base);
 #pragma unroll
@@ -760,40 +786,36 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
             s[2] += dk; s[3] += dk * dk; s[4] += dv; s[5] += dv * dv;
         }
     }
-    ob_block_sum_n<6, 4>(s, red);
-    float mq, rq, mk, rk, mv, rv;
-    ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
-    ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
-    ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
-
-    if (tid < D) {
-        tmp[tid] = (_Float16)ob_ln_apply((float)uqh, mq, rq);
-        tmp[D + tid] = (_Float16)ob_ln_apply((float)ukh, mk, rk);
-        v_s[tid] = (_Float16)ob_ln_apply((float)uvh, mv, rv);
-    }
-    __syncthreads();
-    if (tid < D) {
-        // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16
-        const float c = (float)cosh_, sn = (float)sinh_;
-        const int half = D >> 1;
-        const float qr = tid < half ? -(float)tmp[tid + half] : (float)tmp[tid - half];
-        const float kr = tid < half ? -(float)tmp[D + tid + half] : (float)tmp[D + tid - half];
-        const float qe = ob_round_h(ob_round_h((float)tmp[tid] * c) + ob_round_h(qr * sn));
-        const float ke = ob_round_h(ob_round_h((float)tmp[D + tid] * c) + ob_round_h(kr * sn));
-        q_s[tid] = (_Float16)qe;
-        k_s[tid] = (_Float16)ke;
-        if (head % (H / Hkv) == 0) {      // one workgroup per kv head appends to the cache
-            A.kcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ke;
-            A.vcache[((int64_t)kvh * A.max_len + pos) * D + tid] = v_s[tid];
+    ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);                        // barrier 1
+    if (tid < 128) {
+        float qe = 0.f, ke = 0.f, ve = 0.f;
+        if (tid < D) {
+            float mq, rq, mk, rk, mv, rv;
+            ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
+            ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
+            ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
+            // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16
+            const float c = (float)cosh_, sn = (float)sinh_;
+            const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
+            const float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
+            ve = ob_ln_apply((float)uvh, mv, rv);
+            const float qr = tid < half ? -q1 : q1, kr = tid < half ? -k1 : k1;
+            qe = ob_round_h(ob_round_h(q0 * c) + ob_round_h(qr * sn));
+            ke = ob_round_h(ob_round_h(k0 * c) + ob_round_h(kr * sn));
+            if (head % (H / Hkv) == 0) {      // one workgroup per kv head appends to the cache
+                A.kcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ke;
+                A.vcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ve;
+            }
         }
+        q_s[tid] = (_Float16)qe; k_s[tid] = (_Float16)ke; v_s[tid] = (_Float16)ve;
     }
-    __syncthreads();
+    __syncthreads();                                                 // barrier 2
 
-    // scores: one position per thread; fp32-accumulated dot of fp16 pairs (v_dot2_f32_f16) -> fp16
-    // (matmul output) -> / sqrt(D) -> fp16 (:546)
+    // scores: fp32-accumulated dot of fp16 pairs (v_dot2_f32_f16) -> fp16 (matmul output) -> / sqrt(D)
+    // -> fp16 (:546).  Positions < 128 stay in registers, later ones go through `sc`.
     const float sqrt_d = sqrtf((float)D);
-    float lmax = -INFINITY;
-    auto dot8 = [](const ob_half8 a, const ob_half8 b, float acc) {
+    auto dot8 = [](const ob_half8 a, const ob_half8 b) {
+        float acc = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const ob_half2 x = {a[2 * e], a[2 * e + 1]}, y = {b[2 * e], b[2 * e + 1]};
@@ -801,76 +823,100 @@ __global__ __launch_bounds__(256) void ob_dec_attn_kernel(const ObAttnArgs A)
         }
         return acc;
     };
-    for (int p = tid; p < L; p += 256) {
-        float dot = 0.f;
-        if (p == pos) {
-            for (int i = 0; i < D8; ++i)
-                dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), *reinterpret_cast<const ob_half8 *>(k_s + 8 * i), dot);
-        } else if (p < 256) {
+    const ob_half8 q8 = *reinterpret_cast<const ob_half8 *>(q_s + 8 * ds);       // zero beyond D
+    const ob_half8 kn8 = *reinterpret_cast<const ob_half8 *>(k_s + 8 * ds);
+    const ob_half8 vn8 = *reinterpret_cast<const ob_half8 *>(v_s + 8 * ds);
+    float sreg[4];
+    float lmax = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < D8) dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), kreg[i], dot);
-        } else {
-            const _Float16 *kr = kbase + (int64_t)p * D;
-            for (int i = 0; i < D8; ++i)
-                dot = dot8(*reinterpret_cast<const ob_half8 *>(q_s + 8 * i), *reinterpret_cast<const ob_half8 *>(kr + 8 * i), dot);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int p = pg + 32 * i;
+        const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
         const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
-        sc[p] = sv;
-        lmax = fmaxf(lmax, sv);
+        sreg[i] = p < L ? sv : -INFINITY;
+        lmax = fmaxf(lmax, sreg[i]);
+    }
+    for (int p0 = 128; p0 < L; p0 += 128) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            if (p < L) {
+                const ob_half8 k8 = p == pos ? kn8 : *reinterpret_cast<const ob_half8 *>(kbase + (int64_t)p * D + dcl);
+                const float dot = ob_row_sum(dot8(q8, k8));
+                const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
+                if (ds == 0) sc[p] = sv;
+                lmax = fmaxf(lmax, sv);
+            }
+        }
     }
     // softmax in fp32 (:562), probabilities rounded to fp16
-    lmax = ob_wave_max(lmax);
+    lmax = ob_rows_max(lmax);
     if (lane == 0) red[96 + wave] = lmax;
-    __syncthreads();
-    const float gmax = fmaxf(fmaxf(red[96], red[97]), fmaxf(red[98], red[99]));
-    float ls[1] = {0.f};
-    for (int p = tid; p < L; p += 256) {
-        const float e = __expf(sc[p] - gmax);
-        sc[p] = e;
-        ls[0] += e;
+    __syncthreads();                                                 // barrier 3
+    float gmax;
+    {
+        const ob_float4 m0 = *reinterpret_cast<const ob_float4 *>(red + 96), m1 = *reinterpret_cast<const ob_float4 *>(red + 100);
+        gmax = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
     }
-    ob_block_sum_n<1, 4>(ls, red + 112);
-    const float inv_l = 1.0f / ls[0];
-    for (int p = tid; p < L; p += 256) sc[p] = ob_round_h(sc[p] * inv_l);
-    __syncthreads();
-
-    // out = P . V: thread = (position group pg of 16, 8-dim slice ds of 16); the first 128 positions
-    // come from the registers loaded at kernel entry, later ones by 16-byte loads
-    for (int d0 = 0; d0 < D; d0 += 128) {
-        const int d = d0 + 8 * ds;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (d < D) {
-            if (d0 == 0) {
+    float lsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int p = pg + 16 * i;
-                    if (p < L) {
-                        const float pr = sc[p];
-                        const ob_half8 vv = (p == pos) ? *reinterpret_cast<const ob_half8 *>(v_s + d) : vreg[i];
+    for (int i = 0; i < 4; ++i) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
+    for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
-                    }
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            if (p < L) {                       // sc[p] was written by lane ds == 0 of this same row
+                const float e = __expf(sc[p] - gmax);
+                if (ds == 0) sc[p] = e;
+                lsum += e;
             }
-#pragma unroll 4
-            for (int p = pg + (d0 == 0 ? 128 : 0); p < L; p += 16) {
-                const float pr = sc[p];
-                const ob_half8 vv = (p == pos) ? *reinterpret_cast<const ob_half8 *>(v_s + d)
-                                               : *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + d);
+        }
+    }
+    lsum = ob_rows_sum(lsum);
+    if (lane == 0) red[112 + wave] = lsum;
+    __syncthreads();                                                 // barrier 4
+    float inv_l;
+    {
+        const ob_float4 l0 = *reinterpret_cast<const ob_float4 *>(red + 112), l1 = *reinterpret_cast<const ob_float4 *>(red + 116);
+        inv_l = 1.0f / (((l0[0] + l0[1]) + (l0[2] + l0[3])) + ((l1[0] + l1[1]) + (l1[2] + l1[3])));
+    }
+    // out = P . V over this thread's positions and 8 dims
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = pg + 32 * i;
+        const float pr = ob_round_h(sreg[i] * inv_l);
+        const ob_half8 vv = p == pos ? vn8 : vreg[i];
+        if (p < L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
+        }
+    }
+    for (int p0 = 128; p0 < L; p0 += 128) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            if (p < L) {
+                const float pr = ob_round_h(sc[p] * inv_l);
+                const ob_half8 vv = p == pos ? vn8 : *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + dcl);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) po[pg * D + d + e] = o[e];
         }
     }
-    __syncthreads();
-    if (tid < D) {
-        float o = 0.f;
 #pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) o += po[g2 * D + tid];
-        A.out[head * D + tid] = (_Float16)o;
+    for (int e = 0; e < 8; ++e) o[e] = ob_rows_sum(o[e]);
+    if (lane < 16) {
+        float *dst = po + wave * 128 + 8 * ds;
+        *reinterpret_cast<ob_float4 *>(dst) = (ob_float4){o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<ob_float4 *>(dst + 4) = (ob_float4){o[4], o[5], o[6], o[7]};
+    }
+    __syncthreads();                                                 // barrier 5
+    if (tid < D) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < OB_ATTN_WAVES; ++w) acc += po[w * 128 + tid];
+        A.out[head * D + tid] = (_Float16)acc;
     }
 }
 

@@ -466,7 +466,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
 {
     if (!m || !st || !m->layers) return ob_fail(ONEBIT_E_ARG, "decode_step: null model/state");
     if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
-        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 256 || m->hidden % 8 != 0 ||
+        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
         m->intermediate % 8 != 0 || m->max_len <= 0 || m->vocab <= 0)
         return ob_fail(ONEBIT_E_SHAPE, "decode_step: unsupported model dimensions");
     if (!st->token || !st->pos || !st->hres0 || !st->hres1 || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
@@ -504,9 +504,9 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
-        const size_t attn_lds = 512 + (size_t)10 * D + (size_t)4 * m->max_len + (size_t)64 * D;
+        const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
-        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(256), attn_lds, s, at);
+        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
         // K3: o_proj
         ObGemvArgs o = {};
