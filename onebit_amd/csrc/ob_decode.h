@@ -89,10 +89,13 @@ __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
 __device__ __forceinline__ void ob_ln_stats(float s1, float s2, float c, int n, float eps, float &mean,
                                             float &rstd)
 {
-    const float m1 = s1 / (float)n;
+    // hardware reciprocal / reciprocal square root (1 ulp), as GPU LayerNorm kernels use: the IEEE
+    // division + sqrt sequences are ~40 dependent instructions on every thread's critical path
+    const float inv_n = __builtin_amdgcn_rcpf((float)n);
+    const float m1 = s1 * inv_n;
     mean = c + m1;
-    const float var = fmaxf(s2 / (float)n - m1 * m1, 0.f);
-    rstd = 1.0f / sqrtf(var + eps);
+    const float var = fmaxf(s2 * inv_n - m1 * m1, 0.f);
+    rstd = __builtin_amdgcn_rsqf(var + eps);
 }
 
 __device__ __forceinline__ float ob_ln_apply(float u, float mean, float rstd)
@@ -102,7 +105,7 @@ __device__ __forceinline__ float ob_ln_apply(float u, float mean, float rstd)
 
 __device__ __forceinline__ float ob_silu_h(float x)   // fp16 silu: fp32 math, one rounding
 {
-    return ob_round_h(x / (1.0f + __expf(-x)));
+    return ob_round_h(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)));
 }
 
 // 16 MFMAs for one 512-weight chunk of a 16-row tile.  w4: this lane's 4 packed words (row = lane&15,
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             for (int i = 0; i < 8; ++i) {
                 const float gate = (float)(_Float16)(((float)v0[v][i] - mg) * rg);      // LayerNorm(gate) -> fp16
                 up[i] = (_Float16)(((float)v1[v][i] - mu) * ru);                        // LayerNorm(up)   -> fp16
-                sg[i] = (_Float16)(gate * __frcp_rn(1.0f + __expf(-gate)));             // silu            -> fp16
+                sg[i] = (_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __expf(-gate)));  // silu            -> fp16
             }
             xh[v] = sg * up;                                    // act_fn(gate) * up, modeling_bitllama.py:257
         }
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 64);
-        const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
+        const float rs = __builtin_amdgcn_rsqf(ss[0] * __builtin_amdgcn_rcpf((float)K) + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
             ob_half8 t;
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 
         // 3. MFMA: for every (chunk, word q, half jh): ONE activation read per projection, then one
         //    MFMA per slot back to back -- consecutive instructions hit different accumulators, so
-        //    the matrix pipe never waits on itself.  Invalid slots run on zero weights.
+        //    the matrix pipe never waits on itself.  Invalid slots re-run a valid tile (never stored).
         const int cpc = lane & 3;
         ob_i32x4 acc[MT];
 #pragma unroll
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                             bv[p] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + q * 128 + jh * 16);
 #pragma unroll
                         for (int j = 0; j < MT; ++j) {
-                            const uint32_t w = tval[j] ? wreg[j][ci][q] : 0u;
+                            const uint32_t w = wreg[j][ci][q];          // invalid slots re-read a valid tile; never stored
                             ob_i32x4 av;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
 
     // scores: fp32-accumulated dot of fp16 pairs (v_dot2_f32_f16) -> fp16 (matmul output) -> / sqrt(D)
     // -> fp16 (:546).  Positions < 128 stay in registers, later ones go through `sc`.
-    const float sqrt_d = sqrtf((float)D);
+    const float inv_sqrt_d = __builtin_amdgcn_rsqf((float)D);      // scalar divisor: multiply by the reciprocal
     auto dot8 = [](const ob_half8 a, const ob_half8 b) {
         float acc = 0.f;
 #pragma unroll
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     for (int i = 0; i < 4; ++i) {
         const int p = pg + 32 * i;
         const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
-        const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
+        const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
         sreg[i] = p < L ? sv : -INFINITY;
         lmax = fmaxf(lmax, sreg[i]);
     }
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
             if (p < L) {
                 const ob_half8 k8 = p == pos ? kn8 : *reinterpret_cast<const ob_half8 *>(kbase + (int64_t)p * D + dcl);
                 const float dot = ob_row_sum(dot8(q8, k8));
-                const float sv = ob_round_h(ob_round_h(dot) / sqrt_d);
+                const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
                 if (ds == 0) sc[p] = sv;
                 lmax = fmaxf(lmax, sv);
             }
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
             }
         }
         ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 32);
-        const float rs = rsqrtf(ss[0] / (float)K + A.rms_eps);
+        const float rs = __builtin_amdgcn_rsqf(ss[0] * __builtin_amdgcn_rcpf((float)K) + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < OB_DEC_MAXV; ++v) {
             const int base = (v * OB_DEC_THREADS + tid) * 8;

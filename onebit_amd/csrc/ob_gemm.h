@@ -96,7 +96,11 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         const bool more = ks + 1 < nk;
+#if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 4)
+        if (more && ks == 0) {                                                         // no global traffic after step 1
+#else
         if (more) {
+#endif
             load_step(ks + 1);
             load_w(ks + 1, wnext);
         }
@@ -104,14 +108,26 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
         for (int hf = 0; hf < 2; ++hf) {
             uint32_t e[4][8];
 #pragma unroll
-            for (int rn = 0; rn < 4; ++rn) ob_expand16((wcur[rn] >> (16 * hf)) & 0xffffu, e[rn]);
+            for (int rn = 0; rn < 4; ++rn) {
+#if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[rn][i] = wcur[rn] + i + hf;          // no sign expansion
+#else
+                ob_expand16((wcur[rn] >> (16 * hf)) & 0xffffu, e[rn]);
+#endif
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int s = 2 * hf + s2;
                 ob_half8 bop[4];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
+                for (int rt = 0; rt < 4; ++rt) {
+#if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 2)
+                    bop[rt] = xs[rt];                                                  // no LDS operand reads
+#else
                     bop[rt] = *reinterpret_cast<const ob_half8 *>(&As[cur][wt * 64 + rt * 16 + r][gq * 32 + 8 * s]);
+#endif
+                }
 #pragma unroll
                 for (int rn = 0; rn < 4; ++rn) {
                     ob_u32x4 av = {e[rn][4 * s2 + 0], e[rn][4 * s2 + 1], e[rn][4 * s2 + 2], e[rn][4 * s2 + 3]};

@@ -3,9 +3,16 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from onebit_amd import BitLinearInf, _lib
 from onebit_amd.bitnet import _stream_ptr
+if os.environ.get("OB_EXTRA"):
+    import subprocess
+    so = "/tmp/libonebit_exp.so"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+                           *os.environ["OB_EXTRA"].split(), "-o", so, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
+    _lib.LIB_PATH = so
 dev = torch.device("cuda:0")
 lib = _lib.load()
-for (T, K, N) in [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 4096, 4096), (2048, 4096, 11008), (256, 4096, 11008), (32, 4096, 11008)]:
+SHAPES = [(16384, 4096, 11008)] if os.environ.get("OB_EXTRA") else None
+for (T, K, N) in SHAPES or [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 4096, 4096), (2048, 4096, 11008), (256, 4096, 11008), (32, 4096, 11008)]:
     m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
     m.weight.data = torch.randint(0, 256, (N, K // 8), dtype=torch.uint8, device=dev).view(torch.int8)
     m.input_factor.data = (0.1 * (0.5 + torch.rand(K, device=dev))).half()
