@@ -80,6 +80,10 @@ __device__ __forceinline__ float ob_round_h(float v) { return (float)(_Float16)v
 __device__ __forceinline__ void ob_expand16(uint32_t bits16, uint32_t (&out)[8])
 {
     const uint32_t c = (bits16 & 0x5555u) | ((bits16 & 0xAAAAu) << 15);
+    // (x & mask) | (one & ~mask) with an opaque mask is the bitfield-insert pattern: ONE v_bfi_b32 per
+    // dword instead of v_and + v_or with a literal each (the compiler folds the constant-mask form)
+    uint32_t mask = 0x80008000u;
+    asm("" : "+s"(mask));
 #pragma unroll
-    for (int p = 0; p < 8; ++p) out[p] = ((c << (15 - 2 * p)) & 0x80008000u) | 0x3C003C00u;
+    for (int p = 0; p < 8; ++p) out[p] = ((c << (15 - 2 * p)) & mask) | (0x3C003C00u & ~mask);
 }

@@ -20,15 +20,18 @@
 #define OB_GB_K 128
 #define OB_GB_PITCH 136      // halves per LDS row: 128 + 8 (272 B)
 
-template <bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
+// NWN = waves along n: 2 (128-row tile, 256 threads, 2 workgroups per CU) or 4 (256-row tile, 512
+// threads, 1 workgroup per CU: the activation tile is shared by twice the rows, halving L2 -> CU traffic).
+template <bool PARTIAL, int NWN>
+__global__ __launch_bounds__(NWN * 128, NWN == 2 ? 2 : 1) void ob_gemm_f16_kernel(
     const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ x, int64_t ldx,
     const _Float16 *__restrict__ h, const _Float16 *__restrict__ g, _Float16 *__restrict__ u,
     float *__restrict__ zp, int T, int K, int N, int nbn, int nbt)
 {
     __shared__ __attribute__((aligned(16))) _Float16 As[2][OB_GB_T][OB_GB_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave & 1, wt = wave >> 1;
+    constexpr int NTH = NWN * 128, TILE_N = NWN * 64, NST = 2048 / NTH;      // staging rows per thread
+    const int wn = wave % NWN, wt = wave / NWN;
     const int r = lane & 15, gq = lane >> 4;
 
     // XCD-aware renumbering (bijective for any grid size): XCD x owns a contiguous id range
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
     const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
     const int bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     const int tt = bid / nbn, tn = bid - tt * nbn;          // n fastest: neighbours share the token tile
-    const int n0 = tn * OB_GB_N, t0 = tt * OB_GB_T;
+    const int n0 = tn * TILE_N, t0 = tt * OB_GB_T;
     (void)nbt;
 
     const int nwords = K >> 5;
@@ -44,9 +47,9 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
 
     // staging: thread -> (token st_t + 16 i, halves st_k .. st_k + 7), 16 lanes cover 256 contiguous bytes
     const int st_t = tid >> 4, st_k = (tid & 15) * 8;
-    const _Float16 *xrow[8];
+    const _Float16 *xrow[NST];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xrow[i] = x + (int64_t)min(t0 + st_t + 16 * i, T - 1) * ldx;
+    for (int i = 0; i < NST; ++i) xrow[i] = x + (int64_t)min(t0 + st_t + (NTH / 16) * i, T - 1) * ldx;
 
     // weights: row of tile rn for this lane
     const uint32_t *wrow[4];
@@ -59,38 +62,42 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
 
-    ob_half8 xs[8], hs;
+    ob_half8 xs[NST], hs;
     uint32_t wcur[4], wnext[4];
 
+    // Loads are raw (addresses clamped into the arrays); nothing touches a loaded register until the
+    // MFMA block of the current step has been issued -- a select right behind a load would park the
+    // wave on vmcnt(0) (loads return in order) for a full L2 round trip in every K step.
+    bool kv_ld = true, wv_ld = true;
     auto load_step = [&](int ks) {
         const int k = ks * OB_GB_K + st_k;
-        const bool kv = k < K;                                // K % 8 == 0: the 8 halves are all in or all out
-        const int kc = kv ? k : 0;
+        kv_ld = k < K;                                        // K % 8 == 0: the 8 halves are all in or all out
+        const int kc = kv_ld ? k : 0;
         hs = *reinterpret_cast<const ob_half8 *>(h + kc);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
-            if (!kv) xs[i] = (ob_half8)(_Float16)0;
-        }
+        for (int i = 0; i < NST; ++i) xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
     };
     auto load_w = [&](int ks, uint32_t (&w)[4]) {
         const int word = ks * 4 + gq;
+        wv_ld = word < nwords;
         const int wc = min(word, nwords - 1);
 #pragma unroll
-        for (int rn = 0; rn < 4; ++rn) {
-            const uint32_t v = wrow[rn][wc];
-            w[rn] = word < nwords ? v : 0u;
-        }
+        for (int rn = 0; rn < 4; ++rn) w[rn] = wrow[rn][wc];
     };
     auto store_step = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<ob_half8 *>(&As[buf][st_t + 16 * i][st_k]) = xs[i] * hs;   // fp16(x*h)
+        for (int i = 0; i < NST; ++i) {
+            ob_half8 a = xs[i] * hs;                                                   // fp16(x*h)
+            if (!kv_ld) a = (ob_half8)(_Float16)0;
+            *reinterpret_cast<ob_half8 *>(&As[buf][st_t + (NTH / 16) * i][st_k]) = a;
+        }
     };
 
     load_step(0);
     load_w(0, wcur);
     store_step(0);
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) wcur[rn] = wv_ld ? wcur[rn] : 0u;
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
             load_step(ks + 1);
             load_w(ks + 1, wnext);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             uint32_t e[4][8];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
 #if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 2)
-                    bop[rt] = xs[rt];                                                  // no LDS operand reads
+                    bop[rt] = xs[rt % NST];                                            // no LDS operand reads
 #else
                     bop[rt] = *reinterpret_cast<const ob_half8 *>(&As[cur][wt * 64 + rt * 16 + r][gq * 32 + 8 * s]);
 #endif
@@ -139,10 +147,11 @@ __global__ __launch_bounds__(256, 2) void ob_gemm_f16_kernel(
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
             store_step(cur ^ 1);
 #pragma unroll
-            for (int rn = 0; rn < 4; ++rn) wcur[rn] = wnext[rn];
+            for (int rn = 0; rn < 4; ++rn) wcur[rn] = wv_ld ? wnext[rn] : 0u;
         }
         __syncthreads();
     }

@@ -119,12 +119,23 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                            const void *h, const void *g, void *u, float *zp, int64_t T, int64_t K,
                            int64_t N, hipStream_t s)
 {
-    if (T > 16) {       // batched prefill: 128 x 128 MFMA tiles, weights expanded once per 4 token tiles
-        const int nbn = (int)((N + OB_GB_N - 1) / OB_GB_N), nbt = (int)((T + OB_GB_T - 1) / OB_GB_T);
-        hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL>), dim3((unsigned)(nbn * nbt)), dim3(256), 0, s,
-                           (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
-                           (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
-                           (int)N, nbn, nbt);
+    if (T > 16) {       // batched prefill: MFMA tiles, weights expanded once per 4 token tiles
+        const int nbt = (int)((T + OB_GB_T - 1) / OB_GB_T);
+        static const int wide_env = getenv("OB_GEMM_WIDE") ? atoi(getenv("OB_GEMM_WIDE")) : -1;
+        const bool wide = wide_env >= 0 ? wide_env != 0 : (N >= 2048 && T >= 2048);
+        if (wide) {
+            const int nbn = (int)((N + 255) / 256);
+            hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL, 4>), dim3((unsigned)(nbn * nbt)), dim3(512), 0, s,
+                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
+                               (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
+                               (int)N, nbn, nbt);
+        } else {
+            const int nbn = (int)((N + OB_GB_N - 1) / OB_GB_N);
+            hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL, 2>), dim3((unsigned)(nbn * nbt)), dim3(256), 0, s,
+                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
+                               (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
+                               (int)N, nbn, nbt);
+        }
         return;
     }
     const int fast = (ldw_bytes % 16 == 0) && ob_aligned(packed, 16) && (ldx % 8 == 0);
