@@ -1,0 +1,114 @@
+"""Evaluation callers of the 1-bit model -- SURVEY.md section 8(f) rank 3.
+
+Host-side restatements of the two loops the reference drives its inference model with:
+
+* ``perplexity``  -- the PPL loop of ``evaluation/lm_eval.py:93-128``: the token stream is cut into
+  ``numel // seqlen`` windows, each window is one prefill, the loss is ``nn.CrossEntropyLoss`` over
+  the shifted logits IN THE LOGITS' DTYPE (fp16 for an fp16 model), and -- as the reference does
+  -- the mean over ``seqlen - 1`` predictions is scaled by ``seqlen`` (``:121``), so the reported
+  number is ``exp(sum(nll) / (nsamples * seqlen))`` (``:126``).  ``limit`` reproduces the
+  reference's early exit (``:123``: it stops after window index ``limit``, i.e. ``limit + 1``
+  windows, and still divides by ``nsamples``).
+* ``loglikelihood_tokens`` -- ``BaseLM._loglikelihood_tokens``
+  (``evaluation/lm_eval/models_utils.py:257-438``): requests sorted by descending total length,
+  chunks of ``batch_size``, inputs ``(context + continuation)[-(max_length + 1):][:-1]`` right-padded
+  with token 0 to the first (longest) request of the chunk, one batched prefill WITHOUT an attention
+  mask (causal attention keeps the padding harmless), ``log_softmax`` over the vocabulary, the
+  continuation's log-probabilities summed, plus the "greedy decoding would have produced exactly
+  this continuation" flag.  Results are returned in the callers' order.
+
+Both run prefill-shaped work: T = B * S tokens per 1-bit layer, i.e. the MFMA GEMM of
+``onebit_linear_forward`` with ragged, padded shapes.  The model is called as the reference calls
+its own (``model(inps)`` -> logits ``[B, S, vocab]``); nothing here touches the oracle.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def _model_logits(model, inps: torch.Tensor) -> torch.Tensor:
+    """``LMClass._model_call`` (evaluation/lm_eval/LMClass.py:78-87): logits of one batched prefill."""
+    out = model(inps)
+    return out["logits"] if isinstance(out, dict) else out
+
+
+@torch.no_grad()
+def perplexity(model, token_ids: torch.Tensor, seqlen: int, limit: int = -1,
+               logits_dtype: Optional[torch.dtype] = None) -> float:
+    """PPL of ``token_ids`` ([1, N] long) in windows of ``seqlen`` (lm_eval.py:93-128).
+
+    ``logits_dtype``: dtype the loss is computed in.  The reference computes
+    ``lm_head(hidden_states)`` itself (``:104-105``), so its logits -- and hence the loss -- are
+    in the parameter dtype; pass ``torch.float16`` to reproduce that with a model whose ``forward``
+    returns fp32 logits (``OneBitLlamaForCausalLM`` follows ``BitLlamaForCausalLMInf.forward``,
+    which upcasts).  ``None`` keeps whatever the model returns.
+    """
+    if token_ids.dim() != 2 or token_ids.shape[0] != 1:
+        raise ValueError("token_ids must be [1, N]")
+    nsamples = token_ids.numel() // seqlen
+    if nsamples == 0:
+        raise ValueError("fewer tokens than one window")
+    dev = next(model.parameters()).device
+    loss_fct = nn.CrossEntropyLoss()
+    nlls = []
+    for i in range(nsamples):
+        batch = token_ids[:, i * seqlen:(i + 1) * seqlen].to(dev)
+        logits = _model_logits(model, batch)
+        if logits_dtype is not None:
+            logits = logits.to(logits_dtype)
+        shift_logits = logits[:, :-1, :]
+        shift_labels = batch[:, 1:]
+        loss = loss_fct(shift_logits.reshape(-1, shift_logits.size(-1)), shift_labels.reshape(-1))
+        nlls.append(loss.float() * seqlen)
+        if i == limit:
+            break
+    return float(torch.exp(torch.stack(nlls).sum() / (nsamples * seqlen)).item())
+
+
+@torch.no_grad()
+def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence[int]]], batch_size: int,
+                         max_length: int, vocab_size: Optional[int] = None) -> List[Tuple[float, bool]]:
+    """``[(sum log p(continuation | context), is_greedy)]`` for ``requests = [(context_ids,
+    continuation_ids)]`` (models_utils.py:257-438).  ``vocab_size`` is the reference's
+    ``[:, :, :self.vocab_size]`` slice (tokenizer vocabulary; default: all logits)."""
+    dev = next(model.parameters()).device
+    # Reorderer (models_utils.py:544-568): requests whose concatenated tokens are identical form ONE
+    # group, evaluated once with the first member's (context, continuation) split -- the split is
+    # not part of the key, a quirk kept here -- and groups are ordered by (-length, tokens).
+    groups = {}
+    for i, (ctx, cont) in enumerate(requests):
+        toks = tuple(ctx) + tuple(cont)
+        groups.setdefault((-len(toks), toks), []).append(i)
+    order = sorted(groups)
+    res: List[Optional[Tuple[float, bool]]] = [None] * len(requests)
+    for c0 in range(0, len(order), batch_size):
+        chunk = order[c0:c0 + batch_size]
+        inps, inplens, conts = [], [], []
+        padding_length = None
+        for key in chunk:
+            ctx, cont = (list(t) for t in requests[groups[key][0]])
+            if not ctx or not cont or len(cont) > max_length:
+                raise ValueError("empty context/continuation or continuation longer than max_length")
+            inp = torch.tensor((ctx + cont)[-(max_length + 1):][:-1], dtype=torch.long)
+            inplen = inp.shape[0]
+            padding_length = padding_length if padding_length is not None else inplen
+            inps.append(torch.cat([inp, torch.zeros(padding_length - inplen, dtype=torch.long)]).unsqueeze(0))
+            inplens.append(inplen)
+            conts.append(cont)
+        batched = torch.cat(inps, dim=0).to(dev)
+        multi_logits = F.log_softmax(_model_logits(model, batched), dim=-1).cpu()
+        for key, logits, inplen, cont in zip(chunk, multi_logits, inplens, conts):
+            contlen = len(cont)
+            lg = logits[inplen - contlen:inplen]
+            if vocab_size is not None:
+                lg = lg[:, :vocab_size]
+            cont_t = torch.tensor(cont, dtype=torch.long)
+            is_greedy = bool((lg.argmax(dim=-1) == cont_t).all())
+            lp = torch.gather(lg, 1, cont_t.unsqueeze(-1)).squeeze(-1)
+            for i in groups[key]:
+                res[i] = (float(lp.sum()), is_greedy)
+    return res  # type: ignore[return-value]
