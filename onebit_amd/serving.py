@@ -1,0 +1,189 @@
+"""Continuous batching for the 1-bit model -- SURVEY.md section 8(f) rank 4 / BASELINE config 5
+("mixed prefill + decode continuous batch").  The reference has no counterpart: its ``generate`` is
+one sequence batch per call.
+
+What matters on this hot path: every scheduled token of a step -- whole prompts of newly admitted
+requests AND the single next token of every running request -- goes through each 1-bit projection
+in ONE ``BitLinearInf`` call on the concatenated ``[T, hidden]`` activations, so the packed weights
+(the dominant HBM bytes at small T) are streamed once per step for all sequences; only attention
+is per request (its own KV-cache slot, its own positions).
+
+``Scheduler`` is pure Python (slot admission, step plans, completion) and is unit-tested on the
+CPU; ``ContinuousBatcher`` executes plans on the GPU with the model's own modules and the exact
+op order of ``LlamaAttentionInf.forward`` (modeling_bitllama.py:487-585), so a request's tokens
+equal ``model.generate`` on that request alone up to fp16 accumulation order.
+
+Multi-GPU: requests are independent -- shard them across ranks (one ``ContinuousBatcher`` per
+GPU, weights replicated: 0.8-1.6 GB); there is no data-path collective to add.
+"""
+from __future__ import annotations
+
+import math
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Deque, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .llama import OneBitLlamaForCausalLM, _rotate_half
+
+
+@dataclass
+class Request:
+    rid: int
+    prompt: List[int]
+    max_new_tokens: int
+    out: List[int] = field(default_factory=list)
+    slot: Optional[int] = None
+    pos: int = 0                      # tokens of this request already in its KV-cache slot
+
+    @property
+    def done(self) -> bool:
+        return len(self.out) >= self.max_new_tokens
+
+
+@dataclass
+class Item:                           # one request's share of a step
+    req: Request
+    tokens: List[int]
+    start: int                        # position of tokens[0]
+
+
+class Scheduler:
+    """FIFO admission into ``max_batch`` KV-cache slots; a step schedules the whole prompt of every
+    newly admitted request (bounded by ``max_step_tokens``) plus one token per running request."""
+
+    def __init__(self, max_batch: int, max_len: int, max_step_tokens: Optional[int] = None):
+        if max_batch <= 0 or max_len <= 0:
+            raise ValueError("max_batch and max_len must be positive")
+        self.max_batch, self.max_len = max_batch, max_len
+        self.max_step_tokens = max_step_tokens
+        self.waiting: Deque[Request] = deque()
+        self.running: List[Request] = []
+        self.finished: Dict[int, Request] = {}
+        self._free = list(range(max_batch - 1, -1, -1))
+        self._next = 0
+
+    def add(self, prompt: List[int], max_new_tokens: int) -> int:
+        if not prompt or max_new_tokens <= 0:
+            raise ValueError("empty prompt or max_new_tokens <= 0")
+        if len(prompt) + max_new_tokens - 1 > self.max_len:
+            raise ValueError("request does not fit max_len")
+        if self.max_step_tokens is not None and len(prompt) > self.max_step_tokens:
+            raise ValueError("prompt longer than max_step_tokens")
+        r = Request(self._next, list(prompt), max_new_tokens)
+        self._next += 1
+        self.waiting.append(r)
+        return r.rid
+
+    @property
+    def idle(self) -> bool:
+        return not self.waiting and not self.running
+
+    def plan(self) -> List[Item]:
+        items = [Item(r, [r.out[-1]], r.pos) for r in self.running]          # decode tokens first
+        budget = None if self.max_step_tokens is None else self.max_step_tokens - len(items)
+        while self.waiting and self._free:
+            r = self.waiting[0]
+            if budget is not None and len(r.prompt) > budget:
+                break                                                         # FIFO: no overtaking
+            self.waiting.popleft()
+            r.slot = self._free.pop()
+            self.running.append(r)
+            items.append(Item(r, r.prompt, 0))
+            if budget is not None:
+                budget -= len(r.prompt)
+        return items
+
+    def commit(self, items: List[Item], next_tokens: List[int]) -> List[Request]:
+        """Record the token each scheduled request produced; returns the requests that finished."""
+        done = []
+        for it, t in zip(items, next_tokens):
+            r = it.req
+            r.pos = it.start + len(it.tokens)
+            r.out.append(int(t))
+            if r.done:
+                done.append(r)
+        for r in done:
+            self.running.remove(r)
+            self._free.append(r.slot)
+            self.finished[r.rid] = r
+        return done
+
+
+class ContinuousBatcher:
+    def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
+                 max_step_tokens: Optional[int] = None):
+        p = model.lm_head.weight
+        if not p.is_cuda:
+            raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
+        self.model, self.cfg, self.dev, self.dtype = model, model.config, p.device, p.dtype
+        self.sched = Scheduler(max_batch, max_len, max_step_tokens)
+        cfg = self.cfg
+        shape = (max_batch, cfg.num_key_value_heads, max_len, cfg.head_dim)
+        self.cache = [(torch.zeros(shape, device=self.dev, dtype=self.dtype),
+                       torch.zeros(shape, device=self.dev, dtype=self.dtype)) for _ in range(cfg.num_hidden_layers)]
+        self.cos, self.sin = model._rope_tables(self.dev, self.dtype)
+        self.steps = 0
+        self.tokens_scheduled = 0
+
+    def add_request(self, prompt: List[int], max_new_tokens: int) -> int:
+        return self.sched.add(prompt, max_new_tokens)
+
+    @torch.no_grad()
+    def _forward(self, items: List[Item]) -> torch.Tensor:
+        """fp32 logits [len(items), vocab] of the last scheduled token of every item."""
+        cfg, m = self.cfg, self.model.model
+        H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        ids = torch.tensor([t for it in items for t in it.tokens], device=self.dev, dtype=torch.long)
+        pos = torch.tensor([it.start + j for it in items for j in range(len(it.tokens))], device=self.dev)
+        bounds, a = [], 0
+        for it in items:
+            bounds.append((a, a + len(it.tokens)))
+            a += len(it.tokens)
+        h = m.embed_tokens(ids)                                               # [T, hidden]
+        c, s = self.cos[pos][:, None, :], self.sin[pos][:, None, :]           # [T, 1, D]
+        for layer, (kc, vc) in zip(m.layers, self.cache):
+            att = layer.self_attn
+            x = layer.input_layernorm(h)
+            q = att.q_proj(x).view(-1, H, D)                                  # ONE call per projection for all tokens
+            k = att.k_proj(x).view(-1, Hkv, D)
+            v = att.v_proj(x).view(-1, Hkv, D)
+            q = (q * c) + (_rotate_half(q) * s)
+            k = (k * c) + (_rotate_half(k) * s)
+            o = torch.empty(ids.shape[0], H * D, device=self.dev, dtype=self.dtype)
+            for it, (a, b) in zip(items, bounds):
+                sl, n, L = it.req.slot, b - a, it.start + b - a
+                kc[sl, :, it.start:L] = k[a:b].transpose(0, 1)
+                vc[sl, :, it.start:L] = v[a:b].transpose(0, 1)
+                keys, vals = kc[sl, :, :L], vc[sl, :, :L]                     # [Hkv, L, D]
+                if Hkv != H:
+                    keys = keys.repeat_interleave(H // Hkv, dim=0)
+                    vals = vals.repeat_interleave(H // Hkv, dim=0)
+                w = torch.matmul(q[a:b].transpose(0, 1), keys.transpose(1, 2)) / math.sqrt(D)     # [H, n, L]
+                if n > 1:
+                    mask = torch.full((n, L), torch.finfo(w.dtype).min, device=self.dev, dtype=w.dtype)
+                    w = w + torch.triu(mask, diagonal=it.start + 1)[None]
+                w = nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+                o[a:b] = torch.matmul(w, vals).transpose(0, 1).reshape(n, H * D)
+            h = h + att.o_proj(o)
+            h = h + layer.mlp(layer.post_attention_layernorm(h))
+        last = torch.tensor([b - 1 for _, b in bounds], device=self.dev)
+        return self.model.lm_head(m.norm(h[last])).float()
+
+    def step(self) -> List[Request]:
+        """Schedule and run one step; returns the requests that finished in it."""
+        items = self.sched.plan()
+        if not items:
+            return []
+        logits = self._forward(items)
+        self.steps += 1
+        self.tokens_scheduled += sum(len(it.tokens) for it in items)
+        return self.sched.commit(items, logits.argmax(-1).tolist())
+
+    def run(self) -> Dict[int, List[int]]:
+        """Drain the queue; {request id: generated tokens}."""
+        while not self.sched.idle:
+            self.step()
+        return {rid: r.out for rid, r in self.sched.finished.items()}
