@@ -142,6 +142,15 @@ class ContinuousBatcher:
         for it in items:
             bounds.append((a, a + len(it.tokens)))
             a += len(it.tokens)
+        dec = [i for i, it in enumerate(items) if len(it.tokens) == 1]
+        dec_rows = None
+        if len(dec) > 1:
+            dec_rows = torch.tensor([bounds[i][0] for i in dec], device=self.dev)
+            dec_slots = torch.tensor([items[i].req.slot for i in dec], device=self.dev)
+            dec_start = torch.tensor([items[i].start for i in dec], device=self.dev)
+            Lmax = max(items[i].start for i in dec) + 1
+            dec_mask = (torch.arange(Lmax, device=self.dev)[None, :] > dec_start[:, None])[:, None, None, :]
+            hk = torch.arange(Hkv, device=self.dev)
         h = m.embed_tokens(ids)                                               # [T, hidden]
         c, s = self.cos[pos][:, None, :], self.sin[pos][:, None, :]           # [T, 1, D]
         for layer, (kc, vc) in zip(m.layers, self.cache):
@@ -153,7 +162,23 @@ class ContinuousBatcher:
             q = (q * c) + (_rotate_half(q) * s)
             k = (k * c) + (_rotate_half(k) * s)
             o = torch.empty(ids.shape[0], H * D, device=self.dev, dtype=self.dtype)
+            if dec_rows is not None:
+                # all single-token items at once: padded to the longest context, positions beyond a
+                # request's own length masked to -inf (probability exactly 0, so the result equals
+                # the unpadded computation of LlamaAttentionInf.forward)
+                kc[dec_slots[:, None], hk[None, :], dec_start[:, None]] = k[dec_rows]
+                vc[dec_slots[:, None], hk[None, :], dec_start[:, None]] = v[dec_rows]
+                keys, vals = kc[dec_slots, :, :Lmax], vc[dec_slots, :, :Lmax]          # [Bd, Hkv, Lmax, D]
+                if Hkv != H:
+                    keys = keys.repeat_interleave(H // Hkv, dim=1)
+                    vals = vals.repeat_interleave(H // Hkv, dim=1)
+                w = torch.matmul(q[dec_rows][:, :, None, :], keys.transpose(2, 3)) / math.sqrt(D)   # [Bd, H, 1, Lmax]
+                w = w.masked_fill(dec_mask, float("-inf"))
+                w = nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+                o[dec_rows] = torch.matmul(w, vals).reshape(-1, H * D)
             for it, (a, b) in zip(items, bounds):
+                if b - a == 1 and dec_rows is not None:
+                    continue
                 sl, n, L = it.req.slot, b - a, it.start + b - a
                 kc[sl, :, it.start:L] = k[a:b].transpose(0, 1)
                 vc[sl, :, it.start:L] = v[a:b].transpose(0, 1)
