@@ -290,7 +290,10 @@ def main():
 
     prefill = None
     if not args.no_prefill:
-        prefill = measure_prefill_sharded(cfg, dev, world, rank)
+        try:
+            prefill = measure_prefill_sharded(cfg, dev, world, rank)
+        except Exception as e:              # the decode line must survive a failure of the secondary measurement
+            prefill = {"error": "%s: %s" % (type(e).__name__, e)}
     roof = cpu = None
     if rank == 0:
         if not args.no_roofline:
