@@ -8,6 +8,7 @@ typedef _Float16 ob_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ob_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 ob_half2 __attribute__((ext_vector_type(2)));
 typedef float ob_float4 __attribute__((ext_vector_type(4)));
+typedef float ob_float2 __attribute__((ext_vector_type(2)));
 typedef uint32_t ob_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ob_u32x2 __attribute__((ext_vector_type(2)));
 typedef int32_t ob_i32x4 __attribute__((ext_vector_type(4)));

@@ -85,6 +85,19 @@ __device__ __forceinline__ void ob_block_sum_n(float (&v)[NV], float *red)
     }
 }
 
+// Shifted sums of 8 halves, two lanes of packed fp32 (v_pk_add_f32 / v_pk_fma_f32): s += (u - c),
+// q += (u - c)^2; even and odd elements accumulate separately and are added at the end.
+__device__ __forceinline__ void ob_stats8(const ob_half8 u, float c, ob_float2 &s, ob_float2 &q)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ob_float2 d = {(float)u[2 * i], (float)u[2 * i + 1]};
+        d = d - c;
+        s += d;
+        q = __builtin_elementwise_fma(d, d, q);
+    }
+}
+
 // LayerNorm statistics (mean, rstd) from shifted sums s1 = sum(u - c), s2 = sum((u - c)^2).
 __device__ __forceinline__ void ob_ln_stats(float s1, float s2, float c, int n, float eps, float &mean,
                                             float &rstd)
@@ -101,6 +114,15 @@ __device__ __forceinline__ void ob_ln_stats(float s1, float s2, float c, int n, 
 __device__ __forceinline__ float ob_ln_apply(float u, float mean, float rstd)
 {
     return ob_round_h((u - mean) * rstd);
+}
+
+// The same LayerNorm element as ONE instruction (v_fma_mixlo_f16: fp16 in, fp32 fma, fp16 out):
+// fp16(u * rstd + (-mean * rstd)).  One rounding of the normalised value instead of two; the forms
+// agree except at fp16 rounding ties of the intermediate (~2^-13 of elements, one ulp), the same
+// spread as between LayerNorm implementations of different torch backends.
+__device__ __forceinline__ _Float16 ob_ln_apply_h(_Float16 u, float rstd, float nmr)
+{
+    return (_Float16)__builtin_fmaf((float)u, rstd, nmr);
 }
 
 __device__ __forceinline__ float ob_silu_h(float x)   // fp16 silu: fp32 math, one rounding
@@ -395,31 +417,29 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         __builtin_amdgcn_sched_barrier(0);
     } else if (PRO == OB_P_SWIGLU) {
         const float c0 = (float)c0h, c1 = (float)c1h;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
-            if (valid[v]) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float dg = (float)v0[v][i] - c0, du = (float)v1[v][i] - c1;
-                    s[0] += dg; s[1] = fmaf(dg, dg, s[1]); s[2] += du; s[3] = fmaf(du, du, s[3]);
-                }
-            }
+            if (valid[v]) { ob_stats8(v0[v], c0, sg2, qg2); ob_stats8(v1[v], c1, su2, qu2); }
         }
+        float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
         ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
         load_items(NA, NITEM);
         __builtin_amdgcn_sched_barrier(0);
         float mg, rg, mu, ru;
         ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
         ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
+        const float ng = -mg * rg, nu = -mu * ru;
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
             ob_half8 sg, up;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float gate = (float)(_Float16)(((float)v0[v][i] - mg) * rg);      // LayerNorm(gate) -> fp16
-                up[i] = (_Float16)(((float)v1[v][i] - mu) * ru);                        // LayerNorm(up)   -> fp16
-                sg[i] = (_Float16)(gate * __builtin_amdgcn_rcpf(1.0f + __expf(-gate)));  // silu            -> fp16
+                const _Float16 gh = ob_ln_apply_h(v0[v][i], rg, ng);                     // LayerNorm(gate) -> fp16
+                up[i] = ob_ln_apply_h(v1[v][i], ru, nu);                                // LayerNorm(up)   -> fp16
+                // silu -> fp16: gate * 1 / (1 + 2^(-gate * log2 e)); the fp16 operands ride in the fma_mix forms
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)gh, -1.44269504088896341f, 0.0f));
+                sg[i] = (_Float16)__builtin_fmaf((float)gh, __builtin_amdgcn_rcpf(1.0f + e), 0.0f);
             }
             xh[v] = sg * up;                                    // act_fn(gate) * up, modeling_bitllama.py:257
         }
@@ -427,24 +447,23 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         ob_half8 hv[KV];
         if (PRO == OB_P_RES_LN_RMS) {
             const float c0 = (float)c0h;
-            float s[2] = {0.f, 0.f};
+            ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
-                if (valid[v]) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { const float d = (float)v0[v][i] - c0; s[0] += d; s[1] = fmaf(d, d, s[1]); }
-                }
+                if (valid[v]) ob_stats8(v0[v], c0, s2, q2);
             }
+            float s[2] = {s2[0] + s2[1], q2[0] + q2[1]};
             ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
             load_items(NA, NITEM);
             __builtin_amdgcn_sched_barrier(0);
             float mean, rstd;
             ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
+            const float nmr = -mean * rstd;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
                 ob_half8 ln;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ln[i] = (_Float16)(((float)v0[v][i] - mean) * rstd);
+                for (int i = 0; i < 8; ++i) ln[i] = ob_ln_apply_h(v0[v][i], rstd, nmr);
                 hv[v] = v1[v] + ln;                 // residual + hidden_states, modeling_bitllama.py:912,918
             }
         } else {
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         for (int v = 0; v < KV; ++v) {
             ob_half8 t;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = (_Float16)((float)hv[v][i] * rs);
+            for (int i = 0; i < 8; ++i) t[i] = (_Float16)__builtin_fmaf((float)hv[v][i], rs, 0.0f);   // fp16(h * rsqrt)
             xh[v] = v2[v] * t;
             if (blockIdx.x == 0 && A.hres_out && valid[v]) ob_st8<SD>(A.hres_out + vbase[v], hv[v]);
         }
@@ -774,21 +793,16 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
 
     // LayerNorm statistics of the three rows (each workgroup recomputes them)
     const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8) {
-        const ob_half8 t = *reinterpret_cast<const ob_half8 *>(A.u_q + base);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = (float)t[i] - cq; s[0] += d; s[1] += d * d; }
-    }
+    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
     for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
-        const ob_half8 tk = *reinterpret_cast<const ob_half8 *>(A.u_k + base);
-        const ob_half8 tv = *reinterpret_cast<const ob_half8 *>(A.u_v + base);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float dk = (float)tk[i] - ck, dv = (float)tv[i] - cv;
-            s[2] += dk; s[3] += dk * dk; s[4] += dv; s[5] += dv * dv;
-        }
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
     }
+    float s[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
     ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);                        // barrier 1
     if (tid < 128) {
         float qe = 0.f, ke = 0.f, ve = 0.f;
