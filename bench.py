@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--k-sharded-decode", action="store_true",
+                    help="also time BASELINE config 4: module-path decode with every 1-bit layer K-sharded over the "
+                         "ranks (one all-reduce per BitLinearInf call); extra JSON field, not the headline value")
     return ap.parse_args()
 
 
@@ -188,6 +191,39 @@ def measure_prefill_sharded(cfg, dev, world, rank):
     return res
 
 
+def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
+    """BASELINE config 4: greedy decode with every BitLinearInf K-sharded (onebit_amd/sharded.py,
+    KShardedBitLinear): partial GEMV on the rank's K slice, all-reduce of the [1, N] fp32 partials,
+    g + LayerNorm everywhere.  Module path (torch glue, no HIP graph): the point is the exchange."""
+    import torch.distributed as dist
+    from onebit_amd.llama import build_synthetic_model
+    from onebit_amd.sharded import shard_model_k
+    model = build_synthetic_model(cfg, seed=4242, device=dev)          # same checkpoint on every rank
+    shard_model_k(model, rank, world, mode="allreduce")
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    prompt = torch.randint(0, cfg.vocab_size, (1, prompt_len), generator=g).to(dev)
+    cache = model.new_cache(1, prompt_len + steps + 4)
+    tok = model(prompt, cache)[:, -1].argmax(-1, keepdim=True)
+    for _ in range(2):
+        tok = model(tok, cache)[:, -1].argmax(-1, keepdim=True)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tok = model(tok, cache)[:, -1].argmax(-1, keepdim=True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return {"k_shards": world, "exchange": "all_reduce(fp32 [1,N]) per BitLinearInf call", "steps": steps,
+            "ms_per_token": round(dt / steps * 1e3, 3), "tokens_per_s": round(steps / dt, 2),
+            "collectives_per_token": 7 * cfg.num_hidden_layers if world > 1 else 0, "path": "module (eager)"}
+
+
 def measure_cpu_baseline(cfg):
     """The oracle's reference-style CPU path (dense +-1 matrix rebuilt on every call, then a dense
     fp32 GEMV, *g, LayerNorm -- bitnet.py:98-118 restated in C), single thread, on the 7 projections
@@ -294,6 +330,12 @@ def main():
             prefill = measure_prefill_sharded(cfg, dev, world, rank)
         except Exception as e:              # the decode line must survive a failure of the secondary measurement
             prefill = {"error": "%s: %s" % (type(e).__name__, e)}
+    ksd = None
+    if args.k_sharded_decode:
+        try:
+            ksd = measure_k_sharded_decode(cfg, dev, world, rank, min(args.steps, 16), args.prompt)
+        except Exception as e:
+            ksd = {"error": "%s: %s" % (type(e).__name__, e)}
     roof = cpu = None
     if rank == 0:
         if not args.no_roofline:
@@ -322,6 +364,8 @@ def main():
                           "frac_of_8TBps": round(tok_b * per_gpu_tok_s / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roof, "cpu_baseline": cpu, "prefill_k_sharded": prefill,
         }
+        if ksd is not None:
+            out["decode_k_sharded"] = ksd
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -24,7 +24,8 @@ from typing import Callable, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["KShard", "shard_k", "k_sharded_forward", "hip_partial", "hip_epilogue"]
+__all__ = ["KShard", "shard_k", "k_sharded_forward", "hip_partial", "hip_epilogue", "KShardedBitLinear",
+           "shard_model_k"]
 
 
 @dataclass
@@ -127,3 +128,45 @@ def k_sharded_forward(shard: KShard, x: torch.Tensor, group=None, mode: str = "r
     y = torch.empty((Tp, zp.shape[1]), dtype=x.dtype, device=zp.device)
     dist.all_gather_into_tensor(y, y_mine, group=group)
     return y[:T]
+
+
+class KShardedBitLinear(torch.nn.Module):
+    """A ``BitLinearInf`` whose hidden (K) dimension is split over the ranks of ``group``: the
+    module-level form of BASELINE config 4 ("decode, hidden-dim sharded across 2/4/8 GPUs with an
+    RCCL all-reduce").  Every rank receives the full-width activations (they are the all-reduced
+    output of the previous layer, identical everywhere), uses its K slice of them, and returns the
+    complete output -- so a model whose 1-bit layers are all replaced (``shard_model_k``) computes
+    the same logits on every rank with 1/world of the packed weights resident per GPU.
+
+    For T = 1 each call moves one ``[1, N]`` fp32 vector (20-55 KB at 13B) through an all-reduce,
+    280 times per token: latency-bound and slower than one GPU; the path exists to
+    be measured and for models that do not fit, not as the fast decode path."""
+
+    def __init__(self, full, rank: int, world: int, group=None, mode: str = "allreduce",
+                 partial_fn: Callable = hip_partial, epilogue_fn: Callable = hip_epilogue, copy: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = full.in_features, full.out_features
+        self.shard = shard_k(full.weight.data, full.input_factor.data, full.weight_scale.data,
+                             None if full.bias is None else full.bias.data, rank, world, copy=copy)
+        self.group, self.mode = group, mode
+        self.partial_fn, self.epilogue_fn = partial_fn, epilogue_fn
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lead = x.shape[:-1]
+        y = k_sharded_forward(self.shard, x.reshape(-1, x.shape[-1]), group=self.group, mode=self.mode,
+                              partial_fn=self.partial_fn, epilogue_fn=self.epilogue_fn)
+        return y.reshape(*lead, self.out_features)
+
+
+def shard_model_k(model: torch.nn.Module, rank: int, world: int, **kw) -> torch.nn.Module:
+    """Replace every ``BitLinearInf`` of ``model`` by its K shard for ``rank`` (in place)."""
+    from .bitnet import BitLinearInf
+
+    def visit(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, BitLinearInf):
+                setattr(mod, name, KShardedBitLinear(child, rank, world, **kw))
+            else:
+                visit(child)
+    visit(model)
+    return model

@@ -109,3 +109,52 @@ def test_k_range_partition():
             assert all(a % 32 == 0 and b % 32 == 0 for a, b in edges)
     with pytest.raises(ValueError):
         k_range(40, 0, 2)
+
+
+def _model_worker(rank, world, port, golden_dir, mode, out):
+    """Whole tiny model, every 1-bit layer K-sharded (BASELINE config 4 at toy size): prefill + 4
+    greedy decode steps against the logits recorded from the reference model."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+        from onebit_amd.sharded import KShardedBitLinear, shard_model_k
+        z = np.load(os.path.join(golden_dir, "model_tiny_b.npz"))
+        kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+        model = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float32)
+        model.load_state_dict({k[3:]: (torch.from_numpy(z[k]) if z[k].dtype == np.int8 else torch.from_numpy(z[k]).float())
+                               for k in z.files if k.startswith("sd_")})
+        shard_model_k(model.eval(), rank, world, mode=mode, partial_fn=_np_partial, epilogue_fn=_np_epilogue)
+        n = sum(isinstance(m, KShardedBitLinear) for m in model.modules())
+        assert n == 7 * kw["num_hidden_layers"]
+        ids = torch.from_numpy(z["input_ids"])
+        cache = model.new_cache(1, ids.shape[1] + 8)
+        logits = model(ids, cache)
+        errs = [float(np.abs(logits[0].numpy() - z["prefill_logits_f32"][0]).max())]
+        toks = z["greedy_f32"][0]
+        for i in range(4):
+            lg = model(torch.tensor([[int(toks[i])]]), cache)
+            errs.append(float(np.abs(lg[0, -1].numpy() - z["decode_logits_f32"][0][i]).max()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, errs)
+        assert all(g == errs for g in gathered)                   # every rank computed the same logits
+        if rank == 0:
+            out.put((max(errs), float(np.abs(z["prefill_logits_f32"]).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "rs_ag")])
+def test_k_sharded_model_decode_gloo(golden_dir, world, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, golden_dir, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    err, scale = q.get(timeout=5)
+    assert err <= 2e-3 * max(1.0, scale), (err, scale)
