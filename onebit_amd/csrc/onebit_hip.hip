@@ -119,23 +119,21 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                            const void *h, const void *g, void *u, float *zp, int64_t T, int64_t K,
                            int64_t N, hipStream_t s)
 {
-    if (T > 16) {       // batched prefill: MFMA tiles, weights expanded once per 4 token tiles
-        const int nbt = (int)((T + OB_GB_T - 1) / OB_GB_T);
-        static const int wide_env = getenv("OB_GEMM_WIDE") ? atoi(getenv("OB_GEMM_WIDE")) : -1;
-        const bool wide = wide_env >= 0 ? wide_env != 0 : (N >= 2048 && T >= 2048);
-        if (wide) {
-            const int nbn = (int)((N + 255) / 256);
-            hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL, 4>), dim3((unsigned)(nbn * nbt)), dim3(512), 0, s,
-                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
-                               (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
-                               (int)N, nbn, nbt);
-        } else {
-            const int nbn = (int)((N + OB_GB_N - 1) / OB_GB_N);
-            hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL, 2>), dim3((unsigned)(nbn * nbt)), dim3(256), 0, s,
-                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx,
-                               (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K,
-                               (int)N, nbn, nbt);
-        }
+    if (T >= 2) {       // MFMA GEMM: token tile sized to T (16 / 32 / 64 tokens x 64 rows, or 128 x 128 for prefill)
+#define OB_GEMM_GO(WN_, WT_, RN_, RT_)                                                                         \
+        do {                                                                                                   \
+            const int nbn = (int)((N + WN_ * RN_ * 16 - 1) / (WN_ * RN_ * 16));                                \
+            const int nbt = (int)((T + WT_ * RT_ * 16 - 1) / (WT_ * RT_ * 16));                                \
+            hipLaunchKernelGGL((ob_gemm_f16_kernel<PARTIAL, WN_, WT_, RN_, RT_>), dim3((unsigned)(nbn * nbt)), \
+                               dim3(WN_ * WT_ * 64), 0, s, (const uint32_t *)packed, ldw_bytes / 4,            \
+                               (const _Float16 *)x, ldx, (const _Float16 *)h, (const _Float16 *)g,             \
+                               (_Float16 *)u, zp, (int)T, (int)K, (int)N, nbn, nbt);                           \
+        } while (0)
+        if (T <= 16) OB_GEMM_GO(4, 1, 1, 1);
+        else if (T <= 32) OB_GEMM_GO(4, 1, 1, 2);
+        else if (T <= 64) OB_GEMM_GO(4, 1, 1, 4);
+        else OB_GEMM_GO(2, 2, 4, 4);
+#undef OB_GEMM_GO
         return;
     }
     const int fast = (ldw_bytes % 16 == 0) && ob_aligned(packed, 16) && (ldx % 8 == 0);

@@ -12,7 +12,7 @@ if os.environ.get("OB_EXTRA"):
 dev = torch.device("cuda:0")
 lib = _lib.load()
 SHAPES = [(16384, 4096, 11008)] if os.environ.get("OB_EXTRA") else None
-for (T, K, N) in SHAPES or [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 4096, 4096), (2048, 4096, 11008), (256, 4096, 11008), (32, 4096, 11008)]:
+for (T, K, N) in SHAPES or [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 4096, 4096), (2048, 4096, 11008), (256, 4096, 11008), (64, 4096, 11008), (32, 4096, 11008), (16, 4096, 11008), (8, 4096, 11008), (2, 4096, 11008), (32, 11008, 4096), (32, 4096, 4096), (16, 4096, 4096)]:
     m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
     m.weight.data = torch.randint(0, 256, (N, K // 8), dtype=torch.uint8, device=dev).view(torch.int8)
     m.input_factor.data = (0.1 * (0.5 + torch.rand(K, device=dev))).half()
