@@ -114,7 +114,7 @@ class Scheduler:
 
 class ContinuousBatcher:
     def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
-                 max_step_tokens: Optional[int] = None):
+                 max_step_tokens: Optional[int] = None, use_graph: bool = True):
         p = model.lm_head.weight
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
@@ -127,6 +127,68 @@ class ContinuousBatcher:
         self.cos, self.sin = model._rope_tables(self.dev, self.dtype)
         self.steps = 0
         self.tokens_scheduled = 0
+        # decode-only steps (the steady state) run as ONE HIP graph over static shapes: row i = slot i,
+        # idle slots compute on token 0 at position 0 of their own (unused) cache slot
+        self.use_graph = use_graph
+        self._graph = None
+        self._g_ids = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
+        self._g_pos = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
+        self._g_next = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
+        self.graph_steps = 0
+
+    @torch.no_grad()
+    def _decode_static(self):
+        """One token for every slot (static shapes, no host-side shape dependence): the same
+        arithmetic as the batched decode branch of ``_forward`` with Lmax = max_len."""
+        cfg, m = self.cfg, self.model.model
+        H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        B, Lm = self.sched.max_batch, self.sched.max_len
+        pos = self._g_pos
+        h = m.embed_tokens(self._g_ids)
+        c, s = self.cos[pos][:, None, :], self.sin[pos][:, None, :]
+        rows = torch.arange(B, device=self.dev)
+        hk = torch.arange(Hkv, device=self.dev)
+        mask = (torch.arange(Lm, device=self.dev)[None, :] > pos[:, None])[:, None, None, :]
+        for layer, (kc, vc) in zip(m.layers, self.cache):
+            att = layer.self_attn
+            x = layer.input_layernorm(h)
+            q = att.q_proj(x).view(-1, H, D)
+            k = att.k_proj(x).view(-1, Hkv, D)
+            v = att.v_proj(x).view(-1, Hkv, D)
+            q = (q * c) + (_rotate_half(q) * s)
+            k = (k * c) + (_rotate_half(k) * s)
+            kc[rows[:, None], hk[None, :], pos[:, None]] = k
+            vc[rows[:, None], hk[None, :], pos[:, None]] = v
+            keys, vals = kc, vc
+            if Hkv != H:
+                keys = keys.repeat_interleave(H // Hkv, dim=1)
+                vals = vals.repeat_interleave(H // Hkv, dim=1)
+            w = torch.matmul(q[:, :, None, :], keys.transpose(2, 3)) / math.sqrt(D)
+            w = w.masked_fill(mask, float("-inf"))
+            w = nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+            o = torch.matmul(w, vals).reshape(B, H * D)
+            h = h + att.o_proj(o)
+            h = h + layer.mlp(layer.post_attention_layernorm(h))
+        self._g_next.copy_(self.model.lm_head(m.norm(h)).float().argmax(-1))
+
+    def _graph_step(self, items: List[Item]) -> List[int]:
+        ids = [0] * self.sched.max_batch
+        pos = [0] * self.sched.max_batch
+        for it in items:
+            ids[it.req.slot], pos[it.req.slot] = it.tokens[0], it.start
+        self._g_ids.copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
+        self._g_pos.copy_(torch.tensor(pos, dtype=torch.long), non_blocking=False)
+        if self._graph is None:
+            self._decode_static()                                   # warm-up (allocations, lazy init)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_static()
+            self._graph = g
+        self._graph.replay()
+        self.graph_steps += 1
+        nxt = self._g_next.tolist()
+        return [nxt[it.req.slot] for it in items]
 
     def add_request(self, prompt: List[int], max_new_tokens: int) -> int:
         return self.sched.add(prompt, max_new_tokens)
@@ -202,9 +264,11 @@ class ContinuousBatcher:
         items = self.sched.plan()
         if not items:
             return []
-        logits = self._forward(items)
         self.steps += 1
         self.tokens_scheduled += sum(len(it.tokens) for it in items)
+        if self.use_graph and all(len(it.tokens) == 1 for it in items):
+            return self.sched.commit(items, self._graph_step(items))
+        logits = self._forward(items)
         return self.sched.commit(items, logits.argmax(-1).tolist())
 
     def run(self) -> Dict[int, List[int]]:

@@ -18,8 +18,9 @@ def _model(golden_dir, name, dev):
     return model.to(dev).eval()
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("name", ["a", "b"])
-def test_continuous_batch_matches_single_sequence_generate(golden_dir, name):
+def test_continuous_batch_matches_single_sequence_generate(golden_dir, name, use_graph):
     from onebit_amd.serving import ContinuousBatcher
     dev = torch.device("cuda:0")
     model = _model(golden_dir, name, dev)
@@ -27,10 +28,11 @@ def test_continuous_batch_matches_single_sequence_generate(golden_dir, name):
     g = torch.Generator().manual_seed(5)
     reqs = [(torch.randint(0, V, (n,), generator=g).tolist(), m) for n, m in
             [(8, 6), (1, 9), (13, 3), (5, 1), (20, 7), (2, 12), (9, 5)]]
-    cb = ContinuousBatcher(model, max_batch=3, max_len=40)
+    cb = ContinuousBatcher(model, max_batch=3, max_len=40, use_graph=use_graph)
     rids = [cb.add_request(p, m) for p, m in reqs]
     out = cb.run()
     assert cb.steps < sum(m for _, m in reqs)              # steps were shared between requests
+    assert (cb.graph_steps > 0) == use_graph
     for rid, (p, m) in zip(rids, reqs):
         ref = model.generate(torch.tensor([p], device=dev), m)[0, len(p):].tolist()
         got = out[rid]
