@@ -767,22 +767,24 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     float *sc = po + OB_ATTN_WAVES * 128;                            // [max_len] scores of positions >= 128
 
     // ---- every load of the short-context path is issued here ------------------------------------
-    const int pos = *A.pos;
-    const int L = pos + 1;
+    // The first 128 cached positions are fetched WITHOUT waiting for the position (one dependent
+    // round trip less on the critical path): rows at or beyond it hold stale or never-written
+    // data and are masked below (scores by select, values by branch), only max_len bounds them.
     const int NQ = H * D, NK = Hkv * D;
     const _Float16 *kbase = A.kcache + (int64_t)kvh * A.max_len * D;
     const _Float16 *vbase = A.vcache + (int64_t)kvh * A.max_len * D;
     const int ds = tid & 15, pg = tid >> 4;
     const bool dok = 8 * ds < D;
     const int dcl = dok ? 8 * ds : 0;
-    const int plast = max(pos - 1, 0);
     ob_half8 kreg[4], vreg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t off = (int64_t)min(pg + 32 * i, plast) * D + dcl;
+        const int64_t off = (int64_t)min(pg + 32 * i, A.max_len - 1) * D + dcl;
         kreg[i] = *reinterpret_cast<const ob_half8 *>(kbase + off);
         vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
     }
+    const int pos = *A.pos;
+    const int L = pos + 1;
     const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
     const int half = D >> 1;
     const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
