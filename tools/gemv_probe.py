@@ -2,11 +2,19 @@
 Usage: OB_ABLATE=m python tools/gemv_probe.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("OB_PROFILE_BUILD"):     # profiling build (-DOB_PROFILE_ABLATE: OB_ABLATE=4 / 10+i return at stamp i)
+    import subprocess
+    from onebit_amd import _lib
+    so = "/tmp/libonebit_prof.so"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+                           "-DOB_PROFILE_ABLATE", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
+                           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
+    _lib.LIB_PATH = so
 from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
 from onebit_amd.engine import fused_gemv, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU
 
 dev = torch.device("cuda:0")
-cfg = OneBitLlamaConfig(num_hidden_layers=8)
+cfg = OneBitLlamaConfig(num_hidden_layers=int(os.environ.get("OB_PROBE_LAYERS", "8")))
 model = build_synthetic_model(cfg, seed=1, device=dev)
 H, I = cfg.hidden_size, cfg.intermediate_size
 f16 = torch.float16
