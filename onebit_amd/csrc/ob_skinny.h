@@ -1,0 +1,172 @@
+// Skinny 1-bit GEMM for gfx950, 2 <= T <= 64 tokens (short prompts, batched decode):
+// z[t][n] = sum_k s[n][k] * fp16(x[t][k] * h[k]) on v_mfma_f32_16x16x32_f16, fp32 accumulate.
+//
+// At these sizes the packed matrix (N*K/8 bytes from HBM) is the traffic and latency is the enemy,
+// so the kernel is built from few, large, fully prefetched phases instead of many small K steps:
+//   * workgroup = 4 waves = 64 rows (16 per wave) x all T tokens (RT groups of 16) x all of K;
+//     grid = N / 64 workgroups, one per CU;
+//   * K advances in phases of PK = 2048 / RT elements (2-8 phases for K = 4096): the activation
+//     tile of a phase (16*RT tokens x PK) is loaded coalesced into registers one phase ahead
+//     (16 x 16-byte loads per thread, every thread owns ONE k-piece of all tokens, so one h load
+//     serves them), multiplied by h (the fp16 rounding of bitnet.py:113) and written to padded LDS
+//     rows; the weights of a phase are PK/512 dwordx4 per lane, also one phase ahead;
+//   * per 512-weight chunk a wave expands its 16 rows' signs once and feeds RT token groups;
+//     with fewer than 4 token groups the k-blocks rotate over 4 / RT accumulators per group so
+//     that consecutive MFMAs never wait on each other.
+// Same register-level conventions as ob_gemm.h / ob_decode.h: weights = A operand (row = lane & 15,
+// k-group = lane >> 4), activations = B operand (column = token).
+#pragma once
+#include "ob_common.h"
+
+template <bool PARTIAL, int RT>
+__global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
+    const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ x, int64_t ldx,
+    const _Float16 *__restrict__ h, const _Float16 *__restrict__ g, _Float16 *__restrict__ u,
+    float *__restrict__ zp, int T, int K, int N)
+{
+    constexpr int PK = 2048 / RT;               // k elements per phase
+    constexpr int CPP = PK / 512;               // 512-weight chunks (one dwordx4 per lane) per phase
+    constexpr int TT = 16 * RT;                 // tokens of the tile
+    constexpr int PITCH = PK + 8;               // halves per LDS row (16-byte pad: rows shift by 4 banks)
+    constexpr int NS = 4 / RT;                  // accumulators per token group
+    constexpr int PPR = PK / 8;                 // 16-byte pieces per token row and phase
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *As = reinterpret_cast<_Float16 *>(smem);          // [2][TT][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, gq = lane >> 4;
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int nph = (K + PK - 1) / PK;
+    const int nwords = K >> 5;
+
+    // staging: thread owns k-piece `kp` of token rows tok0 + (256 / PPR) * i
+    const int kp = tid % PPR, tok0 = tid / PPR;
+    constexpr int TSTEP = 256 / PPR;            // 1, 2, 4 for RT = 1, 2, 4
+    const _Float16 *xrow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
+    const uint32_t *wrow = W + (int64_t)min(n0 + r, N - 1) * ldw_words;
+
+    ob_float4 acc[RT][NS];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < NS; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+
+    // raw loads only (clamped addresses); masks are applied after the phase's MFMA block is issued
+    ob_half8 xs[16], hs;
+    ob_u32x4 wcur[CPP], wnext[CPP];
+    bool kv_ld = true;
+    auto load_x = [&](int ph) {
+        const int k = ph * PK + kp * 8;
+        kv_ld = k < K;
+        const int kc = kv_ld ? k : 0;
+        hs = *reinterpret_cast<const ob_half8 *>(h + kc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
+    };
+    auto load_w = [&](int ph, ob_u32x4 (&w)[CPP]) {
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+            const int word = (ph * CPP + c) * 16 + gq * 4;
+            w[c] = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(wrow + min(word, nwords - 4)));
+        }
+    };
+    auto mask_w = [&](int ph, ob_u32x4 (&w)[CPP]) {
+#pragma unroll
+        for (int c = 0; c < CPP; ++c)
+            if ((ph * CPP + c) * 16 + gq * 4 >= nwords) w[c] = (ob_u32x4){0u, 0u, 0u, 0u};
+    };
+    auto store_x = [&](int buf) {
+        _Float16 *dst = As + (size_t)buf * TT * PITCH + kp * 8;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ob_half8 a = xs[i] * hs;                                                   // fp16(x*h)
+            if (!kv_ld) a = (ob_half8)(_Float16)0;
+            *reinterpret_cast<ob_half8 *>(dst + (size_t)(tok0 + TSTEP * i) * PITCH) = a;
+        }
+    };
+
+    load_x(0);
+    load_w(0, wcur);
+    store_x(0);
+    mask_w(0, wcur);
+    __syncthreads();
+
+    for (int ph = 0; ph < nph; ++ph) {
+        const int cur = ph & 1;
+        const bool more = ph + 1 < nph;
+        if (more) {
+            load_x(ph + 1);
+            load_w(ph + 1, wnext);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16 *Ab = As + (size_t)cur * TT * PITCH + (size_t)r * PITCH + gq * 128;
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    uint32_t e[8];
+                    ob_expand16((wcur[c][q] >> (16 * hf)) & 0xffffu, e);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        ob_u32x4 av = {e[4 * s2 + 0], e[4 * s2 + 1], e[4 * s2 + 2], e[4 * s2 + 3]};
+                        ob_half8 aop;
+                        __builtin_memcpy(&aop, &av, 16);
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const ob_half8 bop = *reinterpret_cast<const ob_half8 *>(
+                                Ab + (size_t)rt * 16 * PITCH + c * 512 + q * 32 + (2 * hf + s2) * 8);
+                            acc[rt][(2 * hf + s2) % NS] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, bop, acc[rt][(2 * hf + s2) % NS], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            store_x(cur ^ 1);
+            mask_w(ph + 1, wnext);
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) wcur[c] = wnext[c];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows n0 + 4*gq + i of token 16*rt + r
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        ob_float4 z = acc[rt][0];
+#pragma unroll
+        for (int b = 1; b < NS; ++b) z += acc[rt][b];
+        const int t = rt * 16 + r;
+        if (t >= T) continue;
+        const int nb = n0 + 4 * gq;
+        if (PARTIAL) {
+            if (nb + 3 < N && (N & 3) == 0) {
+                *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = z;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < N) zp[(int64_t)t * N + nb + i] = z[i];
+            }
+        } else {
+            _Float16 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gn = (float)g[min(nb + i, N - 1)];
+                o[i] = (_Float16)(ob_round_h(z[i]) * gn);                  // fp16(z) (:115), * g -> fp16 (:116)
+            }
+            if (nb + 3 < N && (N & 3) == 0) {
+                ob_half4 ov = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<ob_half4 *>(u + (int64_t)t * N + nb) = ov;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (nb + i < N) u[(int64_t)t * N + nb + i] = o[i];
+            }
+        }
+    }
+}

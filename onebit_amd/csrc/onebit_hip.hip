@@ -12,6 +12,7 @@
 #include "ob_pack.h"
 #include "ob_decode.h"
 #include "ob_gemm.h"
+#include "ob_skinny.h"
 
 static thread_local char g_err[256] = "";
 
@@ -129,10 +130,31 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                                (const _Float16 *)x, ldx, (const _Float16 *)h, (const _Float16 *)g,             \
                                (_Float16 *)u, zp, (int)T, (int)K, (int)N, nbn, nbt);                           \
         } while (0)
-        if (T <= 16) OB_GEMM_GO(4, 1, 1, 1);
+        // 2 <= T <= 64 with 16-byte aligned packed rows and K % 128 == 0: the phase-prefetched skinny kernel
+        static const int skinny_env = getenv("OB_SKINNY") ? atoi(getenv("OB_SKINNY")) : 1;
+        const bool skinny = skinny_env && T <= 64 && K % 128 == 0 && K >= 512 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16);
+#define OB_SKINNY_GO(RT_)                                                                                      \
+        do {                                                                                                   \
+            const size_t lds = (size_t)2 * 16 * RT_ * (2048 / RT_ + 8) * 2;                                    \
+            static bool attr_set = false;                                                                      \
+            if (!attr_set) {                                                                                   \
+                (void)hipFuncSetAttribute((const void *)ob_skinny_f16_kernel<PARTIAL, RT_>,                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+                attr_set = true;                                                                               \
+            }                                                                                                  \
+            hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT_>), dim3((unsigned)((N + 63) / 64)),          \
+                               dim3(256), lds, s, (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x,  \
+                               ldx, (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T,       \
+                               (int)K, (int)N);                                                                \
+        } while (0)
+        if (skinny && T <= 16) OB_SKINNY_GO(1);
+        else if (skinny && T <= 32) OB_SKINNY_GO(2);
+        else if (skinny) OB_SKINNY_GO(4);
+        else if (T <= 16) OB_GEMM_GO(4, 1, 1, 1);
         else if (T <= 32) OB_GEMM_GO(4, 1, 1, 2);
         else if (T <= 64) OB_GEMM_GO(4, 1, 1, 4);
         else OB_GEMM_GO(2, 2, 4, 4);
+#undef OB_SKINNY_GO
 #undef OB_GEMM_GO
         return;
     }
