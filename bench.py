@@ -185,6 +185,28 @@ def measure_prefill_sharded(cfg, dev, world, rank):
         tmax = torch.tensor([dt2], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt2 = float(tmax.item())
+    # N-sharded (output rows split): only the LayerNorm statistics cross ranks (2 all-reduces of [T] fp32)
+    try:
+        from onebit_amd.sharded import n_sharded_forward, shard_n
+        nsh = shard_n(W, h, gs, None, rank, world)
+        for _ in range(4):
+            n_sharded_forward(nsh, x)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            n_sharded_forward(nsh, x)
+        fence()
+        dt3 = (time.perf_counter() - t0) / n
+        if world > 1:
+            tmax = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt3 = float(tmax.item())
+        res["n_sharded"] = {"rows_per_rank": nsh.n1 - nsh.n0, "exchange": "all_gather(fp32 [T,2] row statistics); output stays N-sharded",
+                            "ms_per_call": round(dt3 * 1e3, 3), "tokens_per_s": round(T / dt3, 1),
+                            "TFLOPs": round(2.0 * T * K * N / dt3 / 1e12, 1),
+                            "frac_of_mfma_peak": round(2.0 * T * K * N / dt3 / 1e12 / (2500.0 * world), 4)}
+    except Exception as e:
+        res["n_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
     res["token_sharded"] = {"tokens_per_rank": Tl, "ms_per_call": round(dt2 * 1e3, 3), "tokens_per_s": round(Tl * world / dt2, 1),
                             "TFLOPs": round(2.0 * Tl * world * K * N / dt2 / 1e12, 1),
                             "frac_of_mfma_peak": round(2.0 * Tl * world * K * N / dt2 / 1e12 / (2500.0 * world), 4)}

@@ -97,6 +97,21 @@ int onebit_scale_layernorm(const float *z, const void *g, const void *bias_or_nu
                            void *u_or_null, int64_t T, int64_t N, int dtype, float ln_eps,
                            unsigned flags, void *stream);
 
+/* ---- N-sharded (output rows split) LayerNorm, SURVEY.md section 8e "alternatives" -----------
+ * A rank that owns columns [n0, n1) of the output holds u[T, n] (n = n1 - n0, from
+ * onebit_linear_forward with ONEBIT_FLAG_SKIP_LN on its row slice of the packed matrix).  The
+ * LayerNorm of bitnet.py:118 needs statistics of the COMPLETE row, so it is split in two:
+ * onebit_row_stats:      stats[t] = { mean of u[t, :], sum of squared deviations from that mean }
+ *                        of the rank's n columns (fp32, exact two-pass); ranks combine them with
+ *                        the parallel-variance formula (host side, [T, 2] floats per rank).
+ * onebit_normalize_rows: y[t, j] = (u[t, j] - mean[t]) * rstd[t] (+ bias[j]) with the combined
+ *                        row statistics; dtype rounding as in the fused LayerNorm.
+ * u, y: [T, n] contiguous, fp16 or fp32 (dtype); stats, mean, rstd: fp32 device arrays.
+ */
+int onebit_row_stats(const void *u, float *stats, int64_t T, int64_t n, int dtype, void *stream);
+int onebit_normalize_rows(const void *u, const float *mean, const float *rstd, const void *bias_or_null,
+                          void *y, int64_t T, int64_t n, int dtype, void *stream);
+
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's
  * BitLlamaForCausalLMInf (modeling_bitllama.py:1512; decoder layer :856-928, attention

@@ -251,3 +251,32 @@ __global__ __launch_bounds__(256) void ob_layernorm_rows_kernel(
         }
     }
 }
+
+// N-sharded LayerNorm halves (include/onebit.h): one 256-thread workgroup per token row slice.
+template <typename TD>
+__global__ __launch_bounds__(256) void ob_row_stats_kernel(const TD *__restrict__ u, float *__restrict__ stats, int n)
+{
+    __shared__ float red[8];
+    const TD *row = u + (int64_t)blockIdx.x * n;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) s += (float)row[j];
+    const float mean = ob_block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) { const float d = (float)row[j] - mean; q += d * d; }
+    q = ob_block_sum(q, red);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = q; }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void ob_normalize_rows_kernel(const TD *__restrict__ u, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, const TD *__restrict__ bias,
+                                                                TD *__restrict__ y, int n)
+{
+    const int64_t off = (int64_t)blockIdx.x * n;
+    const float m = mean[blockIdx.x], r = rstd[blockIdx.x];
+    for (int j = threadIdx.x; j < n; j += 256) {
+        TD v = (TD)(((float)u[off + j] - m) * r);                   // LayerNorm output in the tensor dtype
+        if (bias) v = (TD)((float)v + (float)bias[j]);              // bias added after, in the tensor dtype (:119-120)
+        y[off + j] = v;
+    }
+}

@@ -307,6 +307,40 @@ extern "C" int onebit_scale_layernorm(const float *z, const void *g, const void 
     return ob_launch_status("scale_layernorm");
 }
 
+extern "C" int onebit_row_stats(const void *u, float *stats, int64_t T, int64_t n, int dtype, void *stream)
+{
+    if (T < 0 || n < 0) return ob_fail(ONEBIT_E_ARG, "row_stats: negative size");
+    if (dtype != ONEBIT_F16 && dtype != ONEBIT_F32) return ob_fail(ONEBIT_E_DTYPE, "row_stats: dtype %d", dtype);
+    if (T == 0) return 0;
+    if (n == 0) return ob_fail(ONEBIT_E_SHAPE, "row_stats: empty rows");
+    if (!u || !stats) return ob_fail(ONEBIT_E_ARG, "row_stats: null pointer");
+    if (T > 0x7fffffffLL || n > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "row_stats: dimension too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ONEBIT_F16)
+        hipLaunchKernelGGL((ob_row_stats_kernel<_Float16>), dim3((unsigned)T), dim3(256), 0, s, (const _Float16 *)u, stats, (int)n);
+    else
+        hipLaunchKernelGGL((ob_row_stats_kernel<float>), dim3((unsigned)T), dim3(256), 0, s, (const float *)u, stats, (int)n);
+    return ob_launch_status("row_stats");
+}
+
+extern "C" int onebit_normalize_rows(const void *u, const float *mean, const float *rstd, const void *bias,
+                                     void *y, int64_t T, int64_t n, int dtype, void *stream)
+{
+    if (T < 0 || n < 0) return ob_fail(ONEBIT_E_ARG, "normalize_rows: negative size");
+    if (dtype != ONEBIT_F16 && dtype != ONEBIT_F32) return ob_fail(ONEBIT_E_DTYPE, "normalize_rows: dtype %d", dtype);
+    if (T == 0 || n == 0) return 0;
+    if (!u || !mean || !rstd || !y) return ob_fail(ONEBIT_E_ARG, "normalize_rows: null pointer");
+    if (T > 0x7fffffffLL || n > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "normalize_rows: dimension too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ONEBIT_F16)
+        hipLaunchKernelGGL((ob_normalize_rows_kernel<_Float16>), dim3((unsigned)T), dim3(256), 0, s, (const _Float16 *)u,
+                           mean, rstd, (const _Float16 *)bias, (_Float16 *)y, (int)n);
+    else
+        hipLaunchKernelGGL((ob_normalize_rows_kernel<float>), dim3((unsigned)T), dim3(256), 0, s, (const float *)u,
+                           mean, rstd, (const float *)bias, (float *)y, (int)n);
+    return ob_launch_status("normalize_rows");
+}
+
 // --------------------------------------------------------------- decode step --
 
 static int ob_cu_count()

@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["KShard", "shard_k", "k_sharded_forward", "hip_partial", "hip_epilogue", "KShardedBitLinear",
-           "shard_model_k"]
+           "shard_model_k", "NShard", "n_range", "shard_n", "n_sharded_forward", "hip_rows_u", "hip_row_stats", "hip_normalize"]
 
 
 @dataclass
@@ -170,3 +170,135 @@ def shard_model_k(model: torch.nn.Module, rank: int, world: int, **kw) -> torch.
                 visit(child)
     visit(model)
     return model
+
+
+# ---------------------------------------------------------------------------------------------------
+# N-sharding (output rows split over ranks): the cheap layout on xGMI.  Rank p owns the packed rows
+# N_p, g[N_p], bias[N_p] and needs the full-width activations; the only cross-rank dependency of a
+# BitLinearInf is the LayerNorm over the complete output row, i.e. TWO numbers per token.  Exchange:
+# one all_gather of [T, 2] fp32 (local mean and sum of squared deviations; 128 KB per rank at
+# T = 16384, against 721 MB of fp32 partials for K-sharding), combined with the parallel-variance
+# formula, and every rank normalises its own columns.  The output stays N-sharded (the natural input of a following K-sharded layer: gate/up
+# N-sharded -> down K-sharded needs no gather in between) or is all-gathered (fp16) on request.
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class NShard:
+    weight: torch.Tensor          # int8 [n1-n0, K/8] (a row slice: contiguous view of the full matrix)
+    input_factor: torch.Tensor    # [K]
+    weight_scale: torch.Tensor    # [n1-n0]
+    bias: Optional[torch.Tensor]  # [n1-n0]
+    n0: int
+    n1: int
+    in_features: int
+    out_features: int
+
+
+def n_range(N: int, rank: int, world: int, granule: int = 16) -> Tuple[int, int]:
+    """Contiguous row slice of `rank`, boundaries on multiples of `granule` (one 16-row MFMA tile)."""
+    units = -(-N // granule)
+    base, extra = divmod(units, world)
+    u0 = rank * base + min(rank, extra)
+    u1 = u0 + base + (1 if rank < extra else 0)
+    return min(u0 * granule, N), min(u1 * granule, N)
+
+
+def shard_n(weight: torch.Tensor, input_factor: torch.Tensor, weight_scale: torch.Tensor,
+            bias: Optional[torch.Tensor], rank: int, world: int) -> NShard:
+    N, KB = weight.shape
+    n0, n1 = n_range(N, rank, world)
+    return NShard(weight[n0:n1], input_factor, weight_scale[n0:n1].contiguous(),
+                  None if bias is None else bias[n0:n1].contiguous(), n0, n1, KB * 8, N)
+
+
+def hip_rows_u(shard: NShard, x: torch.Tensor) -> torch.Tensor:
+    """Pre-LayerNorm u = fp16(fp16(z) * g) of this rank's rows, [T, n1-n0], through the C ABI
+    (onebit_linear_forward with ONEBIT_FLAG_SKIP_LN on the row slice)."""
+    from . import _lib
+    from .bitnet import _dtype_code, _stream_ptr
+    lib = _lib.load()
+    T, K = x.shape
+    n = shard.n1 - shard.n0
+    code = _dtype_code(x.dtype)
+    u = torch.empty((T, n), dtype=x.dtype, device=x.device)
+    ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    w = shard.weight
+    with torch.cuda.device(x.device):
+        rc = lib.onebit_linear_forward(w.data_ptr(), w.stride(0), x.data_ptr(), shard.input_factor.data_ptr(),
+                                       shard.weight_scale.data_ptr(), None, u.data_ptr(), None,
+                                       None if ws is None else ws.data_ptr(), ws_bytes, T, K, n, code, 0.0,
+                                       _lib.FLAG_SKIP_LN, _stream_ptr(x.device))
+    _lib.check(rc, "onebit_linear_forward")
+    return u
+
+
+def hip_row_stats(u: torch.Tensor) -> torch.Tensor:
+    """[T, 2] fp32: mean and sum of squared deviations of every row of u [T, n] (onebit_row_stats)."""
+    from . import _lib
+    from .bitnet import _dtype_code, _stream_ptr
+    lib = _lib.load()
+    T, n = u.shape
+    st = torch.empty((T, 2), dtype=torch.float32, device=u.device)
+    with torch.cuda.device(u.device):
+        rc = lib.onebit_row_stats(u.data_ptr(), st.data_ptr(), T, n, _dtype_code(u.dtype), _stream_ptr(u.device))
+    _lib.check(rc, "onebit_row_stats")
+    return st
+
+
+def hip_normalize(u: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    from . import _lib
+    from .bitnet import _dtype_code, _stream_ptr
+    lib = _lib.load()
+    T, n = u.shape
+    y = torch.empty_like(u)
+    b = None if bias is None else bias.to(u.dtype).contiguous()
+    with torch.cuda.device(u.device):
+        rc = lib.onebit_normalize_rows(u.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None if b is None else b.data_ptr(),
+                                       y.data_ptr(), T, n, _dtype_code(u.dtype), _stream_ptr(u.device))
+    _lib.check(rc, "onebit_normalize_rows")
+    return y
+
+
+def _torch_row_stats(u: torch.Tensor) -> torch.Tensor:          # CPU stand-ins with the same contracts (gloo tests)
+    uf = u.float()
+    mean = uf.mean(dim=-1)
+    return torch.stack([mean, ((uf - mean[:, None]) ** 2).sum(dim=-1)], dim=-1)
+
+
+def _torch_normalize(u, mean, rstd, bias):
+    y = ((u.float() - mean[:, None]) * rstd[:, None]).to(u.dtype)
+    return y if bias is None else y + bias.to(u.dtype)
+
+
+def n_sharded_forward(shard: NShard, x: torch.Tensor, group=None, gather: bool = False, rows_fn: Callable = hip_rows_u,
+                      stats_fn: Callable = hip_row_stats, normalize_fn: Callable = hip_normalize,
+                      eps: float = 1e-5) -> torch.Tensor:
+    """x: [T, K] full-width activations on every rank.  Returns this rank's columns y[:, n0:n1]
+    (``gather=False``) or the complete y [T, N] (``gather=True``, needs equal slices)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    u = rows_fn(shard, x)                                              # [T, n_p] in x.dtype
+    N = shard.out_features
+    st = stats_fn(u)                                                   # [T, 2]: local mean, local M2
+    n_p = float(shard.n1 - shard.n0)
+    if world > 1:
+        # parallel variance (Chan et al.): N*mean = sum n_p*mean_p;  M2 = sum M2_p + sum n_p*(mean_p - mean)^2
+        all_st = torch.empty((world,) + tuple(st.shape), dtype=st.dtype, device=st.device)
+        counts = torch.tensor([n_range(N, r, world)[1] - n_range(N, r, world)[0] for r in range(world)],
+                              dtype=torch.float32, device=st.device).view(world, 1)
+        dist.all_gather_into_tensor(all_st.view(world * st.shape[0], 2), st.contiguous(), group=group)
+        mean = (all_st[:, :, 0] * counts).sum(dim=0) / N
+        m2 = all_st[:, :, 1].sum(dim=0) + (counts * (all_st[:, :, 0] - mean[None]) ** 2).sum(dim=0)
+    else:
+        mean, m2 = st[:, 0].contiguous(), st[:, 1].contiguous()
+        del n_p
+    rstd = torch.rsqrt(m2 / N + eps)
+    y = normalize_fn(u, mean.contiguous(), rstd.contiguous(), shard.bias)
+    if not gather or world == 1:
+        return y
+    n = shard.n1 - shard.n0
+    if n * world != N:
+        raise ValueError("gather=True needs equal row slices")
+    T = y.shape[0]
+    parts = torch.empty((world * T, n), dtype=y.dtype, device=y.device)      # rank-major concatenation
+    dist.all_gather_into_tensor(parts, y.contiguous(), group=group)
+    return parts.view(world, T, n).permute(1, 0, 2).reshape(T, N)

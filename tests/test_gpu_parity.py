@@ -310,3 +310,28 @@ def test_k_sharded_forward_hip_world1(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_n_sharded_rows_match_full_forward():
+    """N-sharding at world size 1 and as two hand-made row slices: every slice's columns, normalised
+    with the statistics of the complete row, equal the full forward (host glue in fp32 torch ops)."""
+    from onebit_amd import BitLinearInf
+    from onebit_amd.sharded import hip_rows_u, n_sharded_forward, shard_n
+    dev = torch.device("cuda:0")
+    K, N, T = 512, 1408, 9
+    g = torch.Generator().manual_seed(3)
+    m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
+    m.weight.data = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8).to(dev)
+    m.input_factor.data = (0.1 * (0.5 + torch.rand(K, generator=g))).half().to(dev)
+    m.weight_scale.data = (0.1 * (0.5 + torch.rand(N, generator=g))).half().to(dev)
+    x = torch.randn(T, K, generator=g).half().to(dev)
+    y = m(x)
+    full = shard_n(m.weight.data, m.input_factor.data, m.weight_scale.data, None, 0, 1)
+    y1 = n_sharded_forward(full, x)
+    assert (y1.float() - y.float()).abs().max() <= 2.5 * FP16_ULP * max(1.0, float(y.abs().max()))
+    # two slices: u of each slice is exactly the corresponding columns of the full pre-LN output
+    m.layernorm = torch.nn.Identity()
+    u = m(x)
+    for r in range(2):
+        sh = shard_n(m.weight.data, m.input_factor.data, m.weight_scale.data, None, r, 2)
+        assert torch.equal(hip_rows_u(sh, x), u[:, sh.n0:sh.n1])

@@ -158,3 +158,72 @@ def test_k_sharded_model_decode_gloo(golden_dir, world, mode):
         assert p.exitcode == 0
     err, scale = q.get(timeout=5)
     assert err <= 2e-3 * max(1.0, scale), (err, scale)
+
+
+def _np_rows_u(shard, x):
+    """Oracle stand-in for hip_rows_u: pre-LayerNorm u of the rank's rows."""
+    from oracle.oracle import np_forward_f16, np_forward_f32
+    fn = np_forward_f16 if x.dtype == torch.float16 else np_forward_f32
+    _, u = fn(shard.weight.numpy(), x.numpy(), shard.input_factor.numpy(), shard.weight_scale.numpy(), None,
+              return_pre_ln=True)
+    return torch.from_numpy(np.ascontiguousarray(u))
+
+
+def _n_worker(rank, world, port, T, K, N, dtype_name, gather, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from onebit_amd.sharded import n_sharded_forward, shard_n
+        dt = torch.float16 if dtype_name == "f16" else torch.float32
+        g = torch.Generator().manual_seed(11)
+        W = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8)
+        h = (0.1 * (0.5 + torch.rand(K, generator=g))).to(dt)
+        gs = (0.1 * (0.5 + torch.rand(N, generator=g))).to(dt)
+        b = (0.1 * torch.randn(N, generator=g)).to(dt)
+        x = torch.randn(T, K, generator=g).to(dt)
+        shard = shard_n(W, h, gs, b, rank, world)
+        assert shard.n0 % 16 == 0 and shard.weight.shape[0] == shard.n1 - shard.n0
+        from onebit_amd.sharded import _torch_normalize, _torch_row_stats
+        y = n_sharded_forward(shard, x, gather=gather, rows_fn=_np_rows_u, stats_fn=_torch_row_stats, normalize_fn=_torch_normalize)
+        from oracle.oracle import COracle
+        c = COracle()
+        fn = c.forward_f16 if dt == torch.float16 else c.forward_f32
+        ref = fn(W.numpy(), x.numpy(), h.numpy(), gs.numpy(), b.numpy()).astype(np.float32)
+        if not gather:
+            ref = ref[:, shard.n0:shard.n1]
+        assert y.shape == ref.shape and y.dtype == dt
+        errs = [None] * world
+        dist.all_gather_object(errs, float(np.abs(y.numpy().astype(np.float32) - ref).max()))
+        if rank == 0:
+            out.put(max(errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,K,N,dtype,gather", [
+    (2, 5, 256, 64, "f16", True),
+    (2, 3, 256, 48, "f32", False),        # uneven rows: 32 + 16
+    (3, 4, 128, 96, "f16", False),
+])
+def test_n_sharded_forward_gloo(world, T, K, N, dtype, gather):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_n_worker, args=(r, world, port, T, K, N, dtype, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    err = q.get(timeout=5)
+    assert err <= (4e-3 if dtype == "f16" else 2e-4), err
+
+
+def test_n_range_partition():
+    from onebit_amd.sharded import n_range
+    for N, world in ((11008, 8), (4096, 4), (5120, 3), (40, 3)):
+        cuts = [n_range(N, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == N
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(c[0] % 16 == 0 for c in cuts)
