@@ -163,6 +163,31 @@ typedef struct onebit_decode_state {
 
 int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t *state, void *stream);
 
+/* ---- batched decode step: one new token for each of B sequences (BASELINE config 5) ----------
+ * The same decoder arithmetic as onebit_decode_step, organised for weight reuse: every 1-bit
+ * projection is ONE skinny-GEMM launch over the [B, K] activations of all sequences (packed
+ * weights streamed once per step), the row-wise glue (residual + LayerNorm + RMSNorm, SiLU * up)
+ * runs once per row, attention once per (head, sequence) on that sequence's KV-cache slot.
+ * 11 launches per decoder layer + the final norm; lm_head / sampling are the caller's (x_out is the
+ * final-norm output [B, hidden], ready for a dense fp16 GEMM).
+ * layer->k_cache / v_cache here are [B][n_kv_heads][max_len][head_dim]; pos[b] < 0 marks an idle
+ * slot (its row is computed but attention and the cache append are skipped).  2 <= B <= 64.
+ */
+typedef struct onebit_batch_state {
+    int32_t batch;              /* B                                                            */
+    const int32_t *tokens;      /* device [B]: token to process per slot                        */
+    const int32_t *pos;         /* device [B]: tokens already cached per slot, < 0 = idle       */
+    void *hres0, *hres1;        /* fp16 [B, hidden] residual stream ping-pong                   */
+    void *x;                    /* fp16 [B, hidden] normalised activations (also the output)    */
+    void *act;                  /* fp16 [B, intermediate] SiLU(gate) * up                       */
+    void *u_q, *u_k, *u_v;      /* fp16 [B, n_heads*head_dim], [B, n_kv*head_dim] x2            */
+    void *attn_out, *u_o;       /* fp16 [B, hidden]                                             */
+    void *u_gate, *u_up;        /* fp16 [B, intermediate]                                       */
+    void *u_down;               /* fp16 [B, hidden]                                             */
+} onebit_batch_state_t;
+
+int onebit_decode_step_batched(const onebit_model_t *model, const onebit_batch_state_t *state, void *stream);
+
 /* One fused decode GEMV launch (the building block of onebit_decode_step, exposed so that a
  * single kernel can be measured and tested in isolation): up to 3 projections sharing the input
  * vector x, each writing its pre-LayerNorm u = fp16(fp16(W.(h*x)) * g) to outs[i] (fp16 [N_i]).

@@ -31,6 +31,7 @@ SYMBOLS = {
     "onebit_row_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_decode_step": (_int, [_vp, _vp, _vp]),      # (onebit_model_t*, onebit_decode_state_t*, stream)
+    "onebit_decode_step_batched": (_int, [_vp, _vp, _vp]),   # (onebit_model_t*, onebit_batch_state_t*, stream)
     "onebit_fused_gemv": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
 }
 

@@ -718,9 +718,11 @@ struct ObAttnArgs {
     const _Float16 *cos, *sin;           // rope tables [max_pos, D] (fp16, as the reference caches them)
     _Float16 *kcache, *vcache;           // [Hkv, max_len, D]
     _Float16 *out;                       // [H*D]
-    const int *pos;                      // device: position of the new token (= tokens already cached)
+    const int *pos;                      // device [slots]: position of the new token (= tokens already cached); < 0 = idle slot
     int H, Hkv, D, max_len;
     float ln_eps;
+    long long slot_stride;               // elements between the caches of consecutive slots (blockIdx.y); rows of
+                                         // u_q / u_k / u_v / out are consecutive per slot
 };
 
 // Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and
@@ -753,12 +755,20 @@ __device__ __forceinline__ float ob_rows_max(float v)
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAttnArgs A)
+__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 {
+    ObAttnArgs A = A_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
     const int head = blockIdx.x, kvh = head / (H / Hkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // sequence slot (batched step): one row of the projections and one cache per slot
+        const int slot = blockIdx.y;
+        A.u_q += (int64_t)slot * H * D; A.u_k += (int64_t)slot * Hkv * D; A.u_v += (int64_t)slot * Hkv * D;
+        A.out += (int64_t)slot * H * D;
+        A.kcache += (int64_t)slot * A.slot_stride; A.vcache += (int64_t)slot * A.slot_stride;
+        A.pos += slot;
+    }
     float *red = reinterpret_cast<float *>(smem);                    // [0,96) stats, [96,104) max, [112,120) sum
     _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);         // [128] query (post RoPE), zero padded
     _Float16 *k_s = q_s + 128;                                       // [128] new key (post RoPE)
@@ -784,6 +794,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
         vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
     }
     const int pos = *A.pos;
+    if (pos < 0) return;                          // idle slot (uniform for the workgroup, before any barrier)
     const int L = pos + 1;
     const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
     const int half = D >> 1;

@@ -13,6 +13,7 @@
 #include "ob_decode.h"
 #include "ob_gemm.h"
 #include "ob_skinny.h"
+#include "ob_batch.h"
 
 static thread_local char g_err[256] = "";
 
@@ -497,6 +498,83 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
     a.xin = (const _Float16 *)x;
     a.rms_eps = 1e-6f; a.ln_eps = 1e-5f;
     return ob_launch_dec_gemv(a, s);
+}
+
+extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
+{
+    if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
+    if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
+        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
+        m->intermediate % 8 != 0 || m->max_len <= 0)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: bad model dimensions");
+    if (st->batch < 2 || st->batch > 64) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: batch %d outside 2..64", st->batch);
+    if (m->hidden > OB_DEC_MAXV * OB_DEC_THREADS * 8 || m->intermediate > OB_DEC_MAXV * OB_DEC_THREADS * 8)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: hidden / intermediate beyond %d", OB_DEC_MAXV * OB_DEC_THREADS * 8);
+    if (!m->layers || !m->embed || !m->final_norm_w || !m->rope_cos || !m->rope_sin || !st->tokens || !st->pos ||
+        !st->hres0 || !st->hres1 || !st->x || !st->act || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
+        !st->u_o || !st->u_gate || !st->u_up || !st->u_down)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = st->batch, H = m->hidden, I = m->intermediate, D = m->head_dim;
+    const int NQ = m->n_heads * D, NK = m->n_kv_heads * D;
+    if (NQ != H) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: n_heads * head_dim != hidden");
+    _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
+    int rc;
+    auto gemm = [&](const onebit_proj_t &p, const void *xin, void *uout, int64_t K, int64_t N, const char *name) -> int {
+        if (!p.weight || !p.input_factor || !p.weight_scale || p.K != K || p.N != N || p.K % 32 != 0 || p.ldw_bytes % 4 != 0 ||
+            p.ldw_bytes < p.K / 8)
+            return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: projection %s has an unexpected shape", name);
+        ob_launch_mm16<false>(p.weight, p.ldw_bytes, xin, K, p.input_factor, p.weight_scale, uout, nullptr, B, K, N, s);
+        return ob_launch_status("decode_step_batched(gemm)");
+    };
+    for (int l = 0; l < m->n_layers; ++l) {
+        const onebit_layer_t &L = m->layers[l];
+        if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
+            return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer in layer %d", l);
+        // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm
+        ObBNormArgs na = {};
+        na.embed = (const _Float16 *)m->embed; na.tokens = st->tokens; na.hres_in = hA; na.u_prev = (const _Float16 *)st->u_down;
+        na.rms_w = (const _Float16 *)L.input_layernorm_w; na.hres_out = hB; na.x = (_Float16 *)st->x; na.H = H;
+        na.rms_eps = m->rms_eps; na.ln_eps = m->ln_eps;
+        if (l == 0) hipLaunchKernelGGL(ob_b_norm_kernel<true>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
+        else hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
+        if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
+        // 2. q, k, v
+        if ((rc = gemm(L.q, st->x, st->u_q, H, NQ, "q"))) return rc;
+        if ((rc = gemm(L.k, st->x, st->u_k, H, NK, "k"))) return rc;
+        if ((rc = gemm(L.v, st->x, st->u_v, H, NK, "v"))) return rc;
+        // 3. attention per (head, slot)
+        ObAttnArgs at = {};
+        at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
+        at.cos = (const _Float16 *)m->rope_cos; at.sin = (const _Float16 *)m->rope_sin;
+        at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
+        at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
+        at.ln_eps = m->ln_eps; at.slot_stride = (long long)m->n_kv_heads * m->max_len * D;
+        const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
+        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
+        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads, B), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+        if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
+        // 4. o_proj
+        if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
+        // 5. residual + LayerNorm(u_o) + post-attention RMSNorm
+        ObBNormArgs nb = na;
+        nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o; nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
+        hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
+        if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
+        // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
+        if ((rc = gemm(L.gate, st->x, st->u_gate, H, I, "gate"))) return rc;
+        if ((rc = gemm(L.up, st->x, st->u_up, H, I, "up"))) return rc;
+        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps};
+        hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
+        if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
+        if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
+    }
+    // final: residual + LayerNorm(u_down) + final RMSNorm -> x
+    ObBNormArgs nf = {};
+    nf.hres_in = hA; nf.u_prev = (const _Float16 *)st->u_down; nf.rms_w = (const _Float16 *)m->final_norm_w; nf.hres_out = hB;
+    nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
+    hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nf);
+    return ob_launch_status("decode_step_batched(final norm)");
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,

@@ -49,6 +49,12 @@ class _State(ctypes.Structure):
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp)]
 
 
+class _BatchState(ctypes.Structure):
+    _fields_ = [("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
+                ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
+                ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp)]
+
+
 class _FusedIn(ctypes.Structure):
     _fields_ = [("xin", _vp), ("embed", _vp), ("hres_in", _vp), ("u_prev", _vp), ("rms_w", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("token", _vp), ("hres_out", _vp),
@@ -204,3 +210,64 @@ class DecodeEngine:
         if n > 0:
             new += self.out_tokens[self._prompt_len:self._prompt_len + n].tolist()
         return torch.cat([input_ids.to(self.dev), torch.tensor([new], device=self.dev, dtype=input_ids.dtype)], dim=1)
+
+
+class BatchedDecodeStep:
+    """``onebit_decode_step_batched`` bound to a model and B KV-cache slots: one new token for every
+    slot per call (skinny 1-bit GEMMs over the [B, hidden] rows, row-wise glue kernels, attention per
+    (head, slot)); the caller owns scheduling, lm_head and sampling.  ``caches[l] = (k, v)`` with k, v
+    ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
+
+    def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int):
+        cfg = model.config
+        p = model.lm_head.weight
+        if not p.is_cuda:
+            raise RuntimeError("BatchedDecodeStep needs the model on a ROCm GPU (no CPU fallback)")
+        if p.dtype != torch.float16:
+            raise ValueError("BatchedDecodeStep needs an fp16 model")
+        if not 2 <= batch <= 64:
+            raise ValueError("batch must be in 2..64")
+        self.model, self.cfg, self.dev, self.batch = model, cfg, p.device, batch
+        self.lib = _lib.load()
+        dev, f16 = self.dev, torch.float16
+        H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        cos, sin = model._rope_tables(dev, f16)
+        self._keep = [cos.contiguous(), sin.contiguous()]
+        layers = (_Layer * cfg.num_hidden_layers)()
+        shape = (batch, cfg.num_key_value_heads, max_len, D)
+        for i, (layer, (kc, vc)) in enumerate(zip(model.model.layers, caches)):
+            if tuple(kc.shape) != shape or tuple(vc.shape) != shape or not kc.is_contiguous() or not vc.is_contiguous():
+                raise ValueError(f"cache {i} must be contiguous {shape}")
+            a, mlp = layer.self_attn, layer.mlp
+            layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
+                               _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
+                               layer.input_layernorm.weight.data_ptr(),
+                               layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
+        self._layers = layers
+        self._model = _Model(cfg.num_hidden_layers, H, I, cfg.num_attention_heads, cfg.num_key_value_heads, D,
+                             cfg.vocab_size, max_len, cfg.rms_norm_eps, 1e-5, layers,
+                             model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
+                             model.lm_head.weight.data_ptr(), self._keep[0].data_ptr(), self._keep[1].data_ptr())
+        z = lambda *n: torch.zeros(*n, dtype=f16, device=dev)
+        Hq, Hkv = cfg.num_attention_heads * D, cfg.num_key_value_heads * D
+        self.tokens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.pos = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        self.buf = dict(hres0=z(batch, H), hres1=z(batch, H), x=z(batch, H), act=z(batch, I), u_q=z(batch, Hq),
+                        u_k=z(batch, Hkv), u_v=z(batch, Hkv), attn_out=z(batch, Hq), u_o=z(batch, H),
+                        u_gate=z(batch, I), u_up=z(batch, I), u_down=z(batch, H))
+        b = self.buf
+        self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
+                                  b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
+                                  b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
+                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr())
+        self.lib.onebit_decode_step_batched.restype = ctypes.c_int
+        self.lib.onebit_decode_step_batched.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_BatchState), _vp]
+
+    def launch(self) -> torch.Tensor:
+        """Enqueue one step on the current stream; returns the final-norm output x [B, hidden]
+        (a view of a persistent buffer: multiply by lm_head^T for logits)."""
+        with torch.cuda.device(self.dev):
+            rc = self.lib.onebit_decode_step_batched(ctypes.byref(self._model), ctypes.byref(self._state),
+                                                     torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "onebit_decode_step_batched")
+        return self.buf["x"]

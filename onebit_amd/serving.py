@@ -114,7 +114,7 @@ class Scheduler:
 
 class ContinuousBatcher:
     def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
-                 max_step_tokens: Optional[int] = None, use_graph: bool = True):
+                 max_step_tokens: Optional[int] = None, use_graph: bool = True, native: bool = True):
         p = model.lm_head.weight
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
@@ -133,13 +133,29 @@ class ContinuousBatcher:
         self._graph = None
         self._g_ids = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
         self._g_pos = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
+        self._g_pos_native = torch.full((max_batch,), -1, dtype=torch.int32, device=self.dev)
         self._g_next = torch.zeros(max_batch, dtype=torch.long, device=self.dev)
         self.graph_steps = 0
+        # native batched step (onebit_decode_step_batched) for the decode-only graph; torch-op glue otherwise
+        self._native = None
+        if native and use_graph and 2 <= max_batch <= 64 and self.dtype == torch.float16 and cfg.head_dim <= 128:
+            from .engine import BatchedDecodeStep
+            try:
+                self._native = BatchedDecodeStep(model, self.cache, max_batch, max_len)
+            except ValueError:                  # shapes the C step does not take (e.g. in_features % 32 != 0)
+                self._native = None
 
     @torch.no_grad()
     def _decode_static(self):
         """One token for every slot (static shapes, no host-side shape dependence): the same
         arithmetic as the batched decode branch of ``_forward`` with Lmax = max_len."""
+        if self._native is not None:
+            # idle slots keep pos = -1: their rows are computed, attention / cache append skipped
+            self._native.tokens.copy_(self._g_ids)
+            self._native.pos.copy_(self._g_pos_native)
+            x = self._native.launch()
+            self._g_next.copy_((x @ self.model.lm_head.weight.t()).float().argmax(-1))
+            return
         cfg, m = self.cfg, self.model.model
         H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         B, Lm = self.sched.max_batch, self.sched.max_len
@@ -178,6 +194,10 @@ class ContinuousBatcher:
             ids[it.req.slot], pos[it.req.slot] = it.tokens[0], it.start
         self._g_ids.copy_(torch.tensor(ids, dtype=torch.long), non_blocking=False)
         self._g_pos.copy_(torch.tensor(pos, dtype=torch.long), non_blocking=False)
+        active = [-1] * self.sched.max_batch
+        for it in items:
+            active[it.req.slot] = it.start
+        self._g_pos_native.copy_(torch.tensor(active, dtype=torch.int32), non_blocking=False)
         if self._graph is None:
             self._decode_static()                                   # warm-up (allocations, lazy init)
             torch.cuda.synchronize(self.dev)

@@ -18,9 +18,9 @@ def _model(golden_dir, name, dev):
     return model.to(dev).eval()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph,native", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("name", ["a", "b"])
-def test_continuous_batch_matches_single_sequence_generate(golden_dir, name, use_graph):
+def test_continuous_batch_matches_single_sequence_generate(golden_dir, name, use_graph, native):
     from onebit_amd.serving import ContinuousBatcher
     dev = torch.device("cuda:0")
     model = _model(golden_dir, name, dev)
@@ -28,7 +28,8 @@ def test_continuous_batch_matches_single_sequence_generate(golden_dir, name, use
     g = torch.Generator().manual_seed(5)
     reqs = [(torch.randint(0, V, (n,), generator=g).tolist(), m) for n, m in
             [(8, 6), (1, 9), (13, 3), (5, 1), (20, 7), (2, 12), (9, 5)]]
-    cb = ContinuousBatcher(model, max_batch=3, max_len=40, use_graph=use_graph)
+    cb = ContinuousBatcher(model, max_batch=3, max_len=40, use_graph=use_graph, native=native)
+    assert (cb._native is not None) == (native and name == "b")     # config a: intermediate 688 is not a multiple of 32
     rids = [cb.add_request(p, m) for p, m in reqs]
     out = cb.run()
     assert cb.steps < sum(m for _, m in reqs)              # steps were shared between requests
