@@ -3,8 +3,10 @@
 //
 // At these sizes the packed matrix (N*K/8 bytes from HBM) is the traffic and latency is the enemy,
 // so the kernel is built from few, large, fully prefetched phases instead of many small K steps:
-//   * workgroup = 4 waves = 64 rows (16 per wave) x all T tokens (RT groups of 16) x all of K;
-//     grid = N / 64 workgroups, one per CU;
+//   * workgroup = 8 waves = 64 rows x all T tokens (RT groups of 16) x all of K: wave (wr, kh) owns
+//     the 16-row tile wr and the k-half kh of every 512-weight chunk (words 2kh, 2kh+1 of the lane's
+//     four), so two waves per SIMD overlap sign expansion, MFMA and LDS reads; the two halves meet
+//     in LDS at the end.  grid = N / 64 workgroups, one per CU;
 //   * K advances in phases of PK = 2048 / RT elements (2-8 phases for K = 4096): the activation
 //     tile of a phase (16*RT tokens x PK) is loaded coalesced into registers one phase ahead
 //     (16 x 16-byte loads per thread, every thread owns ONE k-piece of all tokens, so one h load
@@ -19,7 +21,7 @@
 #include "ob_common.h"
 
 template <bool PARTIAL, int RT>
-__global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
+__global__ __launch_bounds__(512) void ob_skinny_f16_kernel(
     const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ x, int64_t ldx,
     const _Float16 *__restrict__ h, const _Float16 *__restrict__ g, _Float16 *__restrict__ u,
     float *__restrict__ zp, int T, int K, int N)
@@ -34,16 +36,18 @@ __global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
     _Float16 *As = reinterpret_cast<_Float16 *>(smem);          // [2][TT][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, gq = lane >> 4;
-    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int wr = wave & 3, kh = wave >> 2;
+    const int n0 = blockIdx.x * 64 + wr * 16;
     const int nph = (K + PK - 1) / PK;
     const int nwords = K >> 5;
 
-    // staging: thread owns k-piece `kp` of token rows tok0 + (256 / PPR) * i
+    // staging: thread owns k-piece `kp` of token rows tok0 + (512 / PPR) * i
     const int kp = tid % PPR, tok0 = tid / PPR;
-    constexpr int TSTEP = 256 / PPR;            // 1, 2, 4 for RT = 1, 2, 4
-    const _Float16 *xrow[16];
+    constexpr int TSTEP = 512 / PPR;            // 2, 4, 8 for RT = 1, 2, 4
+    constexpr int NSTG = TT / TSTEP;            // 8 loads per thread and phase
+    const _Float16 *xrow[NSTG];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
+    for (int i = 0; i < NSTG; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
     const uint32_t *wrow = W + (int64_t)min(n0 + r, N - 1) * ldw_words;
 
     ob_float4 acc[RT][NS];
@@ -53,8 +57,8 @@ __global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
         for (int b = 0; b < NS; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
 
     // raw loads only (clamped addresses); masks are applied after the phase's MFMA block is issued
-    ob_half8 xs[16], hs;
-    ob_u32x4 wcur[CPP], wnext[CPP];
+    ob_half8 xs[NSTG], hs;
+    ob_u32x2 wcur[CPP], wnext[CPP];
     bool kv_ld = true;
     auto load_x = [&](int ph) {
         const int k = ph * PK + kp * 8;
@@ -62,24 +66,24 @@ __global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
         const int kc = kv_ld ? k : 0;
         hs = *reinterpret_cast<const ob_half8 *>(h + kc);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
+        for (int i = 0; i < NSTG; ++i) xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
     };
-    auto load_w = [&](int ph, ob_u32x4 (&w)[CPP]) {
+    auto load_w = [&](int ph, ob_u32x2 (&w)[CPP]) {
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
             const int word = (ph * CPP + c) * 16 + gq * 4;
-            w[c] = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(wrow + min(word, nwords - 4)));
+            w[c] = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x2 *>(wrow + min(word, nwords - 4) + 2 * kh));
         }
     };
-    auto mask_w = [&](int ph, ob_u32x4 (&w)[CPP]) {
+    auto mask_w = [&](int ph, ob_u32x2 (&w)[CPP]) {
 #pragma unroll
         for (int c = 0; c < CPP; ++c)
-            if ((ph * CPP + c) * 16 + gq * 4 >= nwords) w[c] = (ob_u32x4){0u, 0u, 0u, 0u};
+            if ((ph * CPP + c) * 16 + gq * 4 >= nwords) w[c] = (ob_u32x2){0u, 0u};
     };
     auto store_x = [&](int buf) {
         _Float16 *dst = As + (size_t)buf * TT * PITCH + kp * 8;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NSTG; ++i) {
             ob_half8 a = xs[i] * hs;                                                   // fp16(x*h)
             if (!kv_ld) a = (ob_half8)(_Float16)0;
             *reinterpret_cast<ob_half8 *>(dst + (size_t)(tok0 + TSTEP * i) * PITCH) = a;
@@ -104,11 +108,12 @@ __global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * kh + q2;          // this wave's words of the chunk
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     uint32_t e[8];
-                    ob_expand16((wcur[c][q] >> (16 * hf)) & 0xffffu, e);
+                    ob_expand16((wcur[c][q2] >> (16 * hf)) & 0xffffu, e);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         ob_u32x4 av = {e[4 * s2 + 0], e[4 * s2 + 1], e[4 * s2 + 2], e[4 * s2 + 3]};
@@ -135,12 +140,26 @@ __global__ __launch_bounds__(256) void ob_skinny_f16_kernel(
         __syncthreads();
     }
 
+    // the two k-halves meet in LDS (the activation buffers are free after the last barrier)
+    float *zr = reinterpret_cast<float *>(smem);                // [4 row tiles][RT][64 lanes][4]
+    if (kh == 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            ob_float4 z = acc[rt][0];
+#pragma unroll
+            for (int b = 1; b < NS; ++b) z += acc[rt][b];
+            *reinterpret_cast<ob_float4 *>(zr + ((size_t)(wr * RT + rt) * 64 + lane) * 4) = z;
+        }
+    }
+    __syncthreads();
+    if (kh == 1) return;
     // epilogue: lane holds rows n0 + 4*gq + i of token 16*rt + r
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         ob_float4 z = acc[rt][0];
 #pragma unroll
         for (int b = 1; b < NS; ++b) z += acc[rt][b];
+        z += *reinterpret_cast<const ob_float4 *>(zr + ((size_t)(wr * RT + rt) * 64 + lane) * 4);
         const int t = rt * 16 + r;
         if (t >= T) continue;
         const int nb = n0 + 4 * gq;

@@ -144,7 +144,7 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                 attr_set = true;                                                                               \
             }                                                                                                  \
             hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT_>), dim3((unsigned)((N + 63) / 64)),          \
-                               dim3(256), lds, s, (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x,  \
+                               dim3(512), lds, s, (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x,  \
                                ldx, (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T,       \
                                (int)K, (int)N);                                                                \
         } while (0)
