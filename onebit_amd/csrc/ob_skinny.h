@@ -20,12 +20,33 @@
 #pragma once
 #include "ob_common.h"
 
+// Up to 3 projections that share the activations (q|k|v, gate|up) ride in one launch: workgroup b
+// belongs to the projection whose tile range contains b.
+struct ObSkinnyProj {
+    const uint32_t *W; long long ldw_words;
+    const _Float16 *h, *g;
+    _Float16 *u;
+    int N, tile_end;              // tiles [previous tile_end, tile_end) of the grid
+};
+struct ObSkinnyArgs {
+    ObSkinnyProj p[3];
+    const _Float16 *x; long long ldx;
+    float *zp;                    // PARTIAL (single projection): fp32 sums
+    int T, K;
+};
+
 template <bool PARTIAL, int RT>
-__global__ __launch_bounds__(512) void ob_skinny_f16_kernel(
-    const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ x, int64_t ldx,
-    const _Float16 *__restrict__ h, const _Float16 *__restrict__ g, _Float16 *__restrict__ u,
-    float *__restrict__ zp, int T, int K, int N)
+__global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A)
 {
+    const int pi = (int)blockIdx.x < A.p[0].tile_end ? 0 : ((int)blockIdx.x < A.p[1].tile_end ? 1 : 2);
+    const ObSkinnyProj P = pi == 0 ? A.p[0] : (pi == 1 ? A.p[1] : A.p[2]);
+    const uint32_t *__restrict__ W = P.W;
+    const int64_t ldw_words = P.ldw_words, ldx = A.ldx;
+    const _Float16 *__restrict__ x = A.x, *__restrict__ h = P.h, *__restrict__ g = P.g;
+    _Float16 *__restrict__ u = P.u;
+    float *__restrict__ zp = A.zp;
+    const int T = A.T, K = A.K, N = P.N;
+    const int tile0 = pi == 0 ? 0 : (pi == 1 ? A.p[0].tile_end : A.p[1].tile_end);
     constexpr int PK = 2048 / RT;               // k elements per phase
     constexpr int CPP = PK / 512;               // 512-weight chunks (one dwordx4 per lane) per phase
     constexpr int TT = 16 * RT;                 // tokens of the tile
@@ -37,7 +58,7 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, gq = lane >> 4;
     const int wr = wave & 3, kh = wave >> 2;
-    const int n0 = blockIdx.x * 64 + wr * 16;
+    const int n0 = ((int)blockIdx.x - tile0) * 64 + wr * 16;
     const int nph = (K + PK - 1) / PK;
     const int nwords = K >> 5;
 

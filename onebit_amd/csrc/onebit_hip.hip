@@ -115,6 +115,26 @@ static void ob_launch_simple(const void *packed, int64_t ldw_bytes, const void *
                        (int)T, (int)K, (int)N);
 }
 
+static inline size_t ob_skinny_lds(int rt) { return (size_t)2 * 16 * rt * (2048 / rt + 8) * 2; }
+
+template <bool PARTIAL, int RT>
+static void ob_launch_skinny(const ObSkinnyArgs &ka, int tiles, hipStream_t s)
+{
+    const size_t lds = ob_skinny_lds(RT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)ob_skinny_f16_kernel<PARTIAL, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT>), dim3((unsigned)tiles), dim3(512), lds, s, ka);
+}
+
+static inline bool ob_skinny_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K)
+{
+    static const int skinny_env = getenv("OB_SKINNY") ? atoi(getenv("OB_SKINNY")) : 1;
+    return skinny_env && T >= 2 && T <= 64 && K % 128 == 0 && K >= 512 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16);
+}
+
 // z (fp32 partial, PARTIAL) or u (fp16) for T tokens.
 template <bool PARTIAL>
 static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x, int64_t ldx,
@@ -132,21 +152,15 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
                                (_Float16 *)u, zp, (int)T, (int)K, (int)N, nbn, nbt);                           \
         } while (0)
         // 2 <= T <= 64 with 16-byte aligned packed rows and K % 128 == 0: the phase-prefetched skinny kernel
-        static const int skinny_env = getenv("OB_SKINNY") ? atoi(getenv("OB_SKINNY")) : 1;
-        const bool skinny = skinny_env && T <= 64 && K % 128 == 0 && K >= 512 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16);
+        const bool skinny = ob_skinny_ok(packed, ldw_bytes, T, K);
 #define OB_SKINNY_GO(RT_)                                                                                      \
         do {                                                                                                   \
-            const size_t lds = (size_t)2 * 16 * RT_ * (2048 / RT_ + 8) * 2;                                    \
-            static bool attr_set = false;                                                                      \
-            if (!attr_set) {                                                                                   \
-                (void)hipFuncSetAttribute((const void *)ob_skinny_f16_kernel<PARTIAL, RT_>,                    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-                attr_set = true;                                                                               \
-            }                                                                                                  \
-            hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT_>), dim3((unsigned)((N + 63) / 64)),          \
-                               dim3(512), lds, s, (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x,  \
-                               ldx, (const _Float16 *)h, (const _Float16 *)g, (_Float16 *)u, zp, (int)T,       \
-                               (int)K, (int)N);                                                                \
+            ObSkinnyArgs ka = {};                                                                              \
+            ka.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)h,              \
+                       (const _Float16 *)g, (_Float16 *)u, (int)N, (int)((N + 63) / 64)};                      \
+            ka.p[1] = ka.p[0]; ka.p[2] = ka.p[0];                                                              \
+            ka.x = (const _Float16 *)x; ka.ldx = ldx; ka.zp = zp; ka.T = (int)T; ka.K = (int)K;                \
+            ob_launch_skinny<PARTIAL, RT_>(ka, ka.p[0].tile_end, s);                                           \
         } while (0)
         if (skinny && T <= 16) OB_SKINNY_GO(1);
         else if (skinny && T <= 32) OB_SKINNY_GO(2);
@@ -527,6 +541,41 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ob_launch_mm16<false>(p.weight, p.ldw_bytes, xin, K, p.input_factor, p.weight_scale, uout, nullptr, B, K, N, s);
         return ob_launch_status("decode_step_batched(gemm)");
     };
+    struct P3 { const onebit_proj_t *p[3]; };
+    struct U3 { void *u[3]; };
+    struct N3 { int64_t n[3]; };
+    // projections sharing their input: one skinny launch over all their row tiles, or one launch each
+    auto gemm_multi = [&](P3 ps, U3 us, N3 ns, int np, const void *xin, int64_t K, const char *name) -> int {
+        bool fuse = true;
+        for (int i = 0; i < np; ++i) {
+            const onebit_proj_t &p = *ps.p[i];
+            if (!p.weight || !p.input_factor || !p.weight_scale || p.K != K || p.N != ns.n[i] || p.K % 32 != 0 ||
+                p.ldw_bytes % 4 != 0 || p.ldw_bytes < p.K / 8)
+                return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: projection %s[%d] has an unexpected shape", name, i);
+            fuse = fuse && ob_skinny_ok(p.weight, p.ldw_bytes, B, K);
+        }
+        if (!fuse) {
+            for (int i = 0; i < np; ++i) {
+                const onebit_proj_t &p = *ps.p[i];
+                ob_launch_mm16<false>(p.weight, p.ldw_bytes, xin, K, p.input_factor, p.weight_scale, us.u[i], nullptr, B, K, p.N, s);
+            }
+            return ob_launch_status("decode_step_batched(gemm)");
+        }
+        ObSkinnyArgs ka = {};
+        int tiles = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int j = i < np ? i : np - 1;
+            const onebit_proj_t &p = *ps.p[j];
+            if (i < np) tiles += (int)((p.N + 63) / 64);
+            ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.input_factor,
+                       (const _Float16 *)p.weight_scale, (_Float16 *)us.u[j], (int)p.N, tiles};
+        }
+        ka.x = (const _Float16 *)xin; ka.ldx = K; ka.zp = nullptr; ka.T = B; ka.K = (int)K;
+        if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
+        else if (B <= 32) ob_launch_skinny<false, 2>(ka, tiles, s);
+        else ob_launch_skinny<false, 4>(ka, tiles, s);
+        return ob_launch_status("decode_step_batched(gemm)");
+    };
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -539,10 +588,8 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if (l == 0) hipLaunchKernelGGL(ob_b_norm_kernel<true>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
         else hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
         if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
-        // 2. q, k, v
-        if ((rc = gemm(L.q, st->x, st->u_q, H, NQ, "q"))) return rc;
-        if ((rc = gemm(L.k, st->x, st->u_k, H, NK, "k"))) return rc;
-        if ((rc = gemm(L.v, st->x, st->u_v, H, NK, "v"))) return rc;
+        // 2. q, k, v: one launch when the skinny kernel takes all three
+        if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, 3, st->x, H, "qkv"))) return rc;
         // 3. attention per (head, slot)
         ObAttnArgs at = {};
         at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
@@ -562,8 +609,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
-        if ((rc = gemm(L.gate, st->x, st->u_gate, H, I, "gate"))) return rc;
-        if ((rc = gemm(L.up, st->x, st->u_up, H, I, "up"))) return rc;
+        if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, 2, st->x, H, "gate|up"))) return rc;
         ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps};
         hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
