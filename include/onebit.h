@@ -168,7 +168,7 @@ int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t 
  * projection is ONE skinny-GEMM launch over the [B, K] activations of all sequences (packed
  * weights streamed once per step), the row-wise glue (residual + LayerNorm + RMSNorm, SiLU * up)
  * runs once per row, attention once per (head, sequence) on that sequence's KV-cache slot.
- * 11 launches per decoder layer + the final norm; lm_head / sampling are the caller's (x_out is the
+ * 8 launches per decoder layer (q|k|v and gate|up share one launch each) + the final norm; lm_head / sampling are the caller's (x_out is the
  * final-norm output [B, hidden], ready for a dense fp16 GEMM).
  * layer->k_cache / v_cache here are [B][n_kv_heads][max_len][head_dim]; pos[b] < 0 marks an idle
  * slot (its row is computed but attention and the cache append are skipped).  2 <= B <= 64.
