@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-serve", action="store_true", help="skip the continuous-batching (config 5) field")
     ap.add_argument("--k-sharded-decode", action="store_true",
                     help="also time BASELINE config 4: module-path decode with every 1-bit layer K-sharded over the "
                          "ranks (one all-reduce per BitLinearInf call); extra JSON field, not the headline value")
@@ -246,6 +247,28 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
             "collectives_per_token": 7 * cfg.num_hidden_layers if world > 1 else 0, "path": "module (eager)"}
 
 
+def measure_continuous_batch(model, dev, slots=32, steps=40):
+    """BASELINE config 5 shape on this model: `slots` sequences decoding together through
+    onebit_decode_step_batched (one HIP-graph replay per step); steady-state decode steps only."""
+    from onebit_amd.serving import ContinuousBatcher
+    cfg = model.config
+    g = torch.Generator(device="cpu").manual_seed(3)
+    cb = ContinuousBatcher(model, max_batch=slots, max_len=16 + steps + 16)
+    for _ in range(slots):
+        cb.add_request(torch.randint(0, cfg.vocab_size, (16,), generator=g).tolist(), steps + 12)
+    for _ in range(6):
+        cb.step()                                   # prefill step, graph capture, warm replays
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cb.step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"slots": slots, "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(slots / dt, 1),
+            "engine": "onebit_decode_step_batched" if cb._native is not None else "torch glue",
+            "note": "steady-state decode, all slots active, greedy; per GPU"}
+
+
 def measure_cpu_baseline(cfg):
     """The oracle's reference-style CPU path (dense +-1 matrix rebuilt on every call, then a dense
     fp32 GEMV, *g, LayerNorm -- bitnet.py:98-118 restated in C), single thread, on the 7 projections
@@ -358,6 +381,12 @@ def main():
             ksd = measure_k_sharded_decode(cfg, dev, world, rank, min(args.steps, 16), args.prompt)
         except Exception as e:
             ksd = {"error": "%s: %s" % (type(e).__name__, e)}
+    serve = None
+    if not args.no_serve and rank == 0:
+        try:
+            serve = measure_continuous_batch(model, dev)
+        except Exception as e:
+            serve = {"error": "%s: %s" % (type(e).__name__, e)}
     roof = cpu = None
     if rank == 0:
         if not args.no_roofline:
@@ -388,6 +417,8 @@ def main():
         }
         if ksd is not None:
             out["decode_k_sharded"] = ksd
+        if serve is not None:
+            out["continuous_batch"] = serve
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
