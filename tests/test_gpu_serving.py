@@ -42,3 +42,29 @@ def test_continuous_batch_matches_single_sequence_generate(golden_dir, name, use
             j = next(i for i in range(m) if got[i] != ref[i])
             lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
             assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
+
+
+def test_native_batched_step_on_7b_shaped_layers():
+    """onebit_decode_step_batched with real layer widths (hidden 4096 / intermediate 11008 / head_dim
+    128, 2 layers), 5 slots of which one stays idle, requests of different lengths: tokens equal
+    single-sequence generate (fp16 near-ties tolerated at the first divergence)."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.serving import ContinuousBatcher
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=512, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+                            num_attention_heads=32, max_position_embeddings=64)
+    model = build_synthetic_model(cfg, seed=3, device=dev)
+    g = torch.Generator().manual_seed(8)
+    reqs = [(torch.randint(0, 512, (n,), generator=g).tolist(), m) for n, m in [(6, 8), (1, 5), (11, 8), (3, 2)]]
+    cb = ContinuousBatcher(model, max_batch=5, max_len=32)
+    assert cb._native is not None
+    rids = [cb.add_request(p, m) for p, m in reqs]
+    out = cb.run()
+    assert cb.graph_steps > 0
+    for rid, (p, m) in zip(rids, reqs):
+        ref = model.generate(torch.tensor([p], device=dev), m)[0, len(p):].tolist()
+        got = out[rid]
+        if got != ref:
+            j = next(i for i in range(m) if got[i] != ref[i])
+            lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
+            assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
