@@ -7,9 +7,9 @@
 //     the 16-row tile wr and the k-half kh of every 512-weight chunk (words 2kh, 2kh+1 of the lane's
 //     four), so two waves per SIMD overlap sign expansion, MFMA and LDS reads; the two halves meet
 //     in LDS at the end.  grid = N / 64 workgroups, one per CU;
-//   * K advances in phases of PK = 2048 / RT elements (2-8 phases for K = 4096): the activation
+//   * K advances in phases of PK = 1024 / RT (RT = 4: 512) elements: the activation
 //     tile of a phase (16*RT tokens x PK) is loaded coalesced into registers one phase ahead
-//     (16 x 16-byte loads per thread, every thread owns ONE k-piece of all tokens, so one h load
+//     (4-8 x 16-byte loads per thread, every thread owns ONE k-piece of its tokens, so one h load
 //     serves them), multiplied by h (the fp16 rounding of bitnet.py:113) and written to padded LDS
 //     rows; the weights of a phase are PK/512 dwordx4 per lane, also one phase ahead;
 //   * per 512-weight chunk a wave expands its 16 rows' signs once and feeds RT token groups;
@@ -35,6 +35,11 @@ struct ObSkinnyArgs {
     int T, K;
 };
 
+// tokens x k elements of one phase: 16 x 1024 / 32 x 512 (66 KB of LDS: two workgroups per CU, so a
+// grid of up to 512 tiles is resident at once and one workgroup's loads hide behind the other's
+// MFMAs) or 64 x 512 (133 KB, one workgroup per CU)
+#define OB_SKINNY_PKT(RT_) ((RT_) == 4 ? 2048 : 1024)
+
 template <bool PARTIAL, int RT>
 __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A)
 {
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     float *__restrict__ zp = A.zp;
     const int T = A.T, K = A.K, N = P.N;
     const int tile0 = pi == 0 ? 0 : (pi == 1 ? A.p[0].tile_end : A.p[1].tile_end);
-    constexpr int PK = 2048 / RT;               // k elements per phase
+    constexpr int PK = OB_SKINNY_PKT(RT) / RT;  // k elements per phase
     constexpr int CPP = PK / 512;               // 512-weight chunks (one dwordx4 per lane) per phase
     constexpr int TT = 16 * RT;                 // tokens of the tile
     constexpr int PITCH = PK + 8;               // halves per LDS row (16-byte pad: rows shift by 4 banks)
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     // staging: thread owns k-piece `kp` of token rows tok0 + (512 / PPR) * i
     const int kp = tid % PPR, tok0 = tid / PPR;
     constexpr int TSTEP = 512 / PPR;            // 2, 4, 8 for RT = 1, 2, 4
-    constexpr int NSTG = TT / TSTEP;            // 8 loads per thread and phase
+    constexpr int NSTG = TT / TSTEP;            // 4 (RT = 1, 2) or 8 (RT = 4) loads per thread and phase
     const _Float16 *xrow[NSTG];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
