@@ -13,7 +13,9 @@ struct ObBNormArgs {
     const _Float16 *embed;        // EMBED: [vocab, H]
     const int *tokens;            // EMBED: [B]
     const _Float16 *hres_in;      // !EMBED: [B, H]
-    const _Float16 *u_prev;       // !EMBED: [B, H] pre-LayerNorm output of the previous projection
+    const _Float16 *u_prev;       // !EMBED: [B, H] pre-LayerNorm output of the previous projection, or NULL with
+    const float *z0, *z1;         //   fp32 split-K partial sums [B, H] of it (u = fp16(fp16(z0 + z1) * g_prev))
+    const _Float16 *g_prev;       //   and its weight_scale [H]
     const _Float16 *rms_w;        // [H]
     _Float16 *hres_out;           // [B, H]
     _Float16 *x;                  // [B, H]
@@ -35,10 +37,27 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         valid[v] = base < H;
         hv[v] = *reinterpret_cast<const ob_half8 *>(src + (valid[v] ? base : 0));
-        if (!EMBED) uv[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + row + (valid[v] ? base : 0));
+        if (!EMBED) {
+            const int b0 = valid[v] ? base : 0;
+            if (A.u_prev) {
+                uv[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + row + b0);
+            } else {                                // split-K partials: the epilogue of bitnet.py:115-116 happens here
+                const ob_half8 gv = *reinterpret_cast<const ob_half8 *>(A.g_prev + b0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z0 + row + b0 + 4 * q);
+                    const ob_float4 b = *reinterpret_cast<const ob_float4 *>(A.z1 + row + b0 + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        uv[v][4 * q + i] = (_Float16)(ob_round_h(a[i] + b[i]) * (float)gv[4 * q + i]);
+                }
+            }
+        }
     }
     if (!EMBED) {
-        const float c0 = (float)A.u_prev[row];
+        // pivot of the shifted sums = element 0 of the row, the same value in every thread
+        const float c0 = A.u_prev ? (float)A.u_prev[row]
+                                  : (float)(_Float16)(ob_round_h(A.z0[row] + A.z1[row]) * (float)A.g_prev[0]);
         ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < OB_DEC_MAXV; ++v)

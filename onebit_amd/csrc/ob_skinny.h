@@ -22,17 +22,20 @@
 
 // Up to 3 projections that share the activations (q|k|v, gate|up) ride in one launch: workgroup b
 // belongs to the projection whose tile range contains b.
+// An entry may also be a K-slice of a projection (W, h, x advanced to the slice, K = its length,
+// PARTIAL output): split-K over workgroups for short-and-wide layers (down_proj), summed by the consumer.
 struct ObSkinnyProj {
     const uint32_t *W; long long ldw_words;
     const _Float16 *h, *g;
-    _Float16 *u;
-    int N, tile_end;              // tiles [previous tile_end, tile_end) of the grid
+    const _Float16 *x;            // activations [T, ldx] (already advanced to the K-slice)
+    _Float16 *u;                  // !PARTIAL: fp16 [T, N]
+    float *zp;                    // PARTIAL: fp32 sums [T, N]
+    int N, K, tile_end;           // tiles [previous tile_end, tile_end) of the grid
 };
 struct ObSkinnyArgs {
     ObSkinnyProj p[3];
-    const _Float16 *x; long long ldx;
-    float *zp;                    // PARTIAL (single projection): fp32 sums
-    int T, K;
+    long long ldx;
+    int T;
 };
 
 // tokens x k elements of one phase: 16 x 1024 / 32 x 512 (66 KB of LDS: two workgroups per CU, so a
@@ -47,10 +50,10 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     const ObSkinnyProj P = pi == 0 ? A.p[0] : (pi == 1 ? A.p[1] : A.p[2]);
     const uint32_t *__restrict__ W = P.W;
     const int64_t ldw_words = P.ldw_words, ldx = A.ldx;
-    const _Float16 *__restrict__ x = A.x, *__restrict__ h = P.h, *__restrict__ g = P.g;
+    const _Float16 *__restrict__ x = P.x, *__restrict__ h = P.h, *__restrict__ g = P.g;
     _Float16 *__restrict__ u = P.u;
-    float *__restrict__ zp = A.zp;
-    const int T = A.T, K = A.K, N = P.N;
+    float *__restrict__ zp = P.zp;
+    const int T = A.T, K = P.K, N = P.N;
     const int tile0 = pi == 0 ? 0 : (pi == 1 ? A.p[0].tile_end : A.p[1].tile_end);
     constexpr int PK = OB_SKINNY_PKT(RT) / RT;  // k elements per phase
     constexpr int CPP = PK / 512;               // 512-weight chunks (one dwordx4 per lane) per phase

@@ -157,9 +157,10 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
         do {                                                                                                   \
             ObSkinnyArgs ka = {};                                                                              \
             ka.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)h,              \
-                       (const _Float16 *)g, (_Float16 *)u, (int)N, (int)((N + 63) / 64)};                      \
+                       (const _Float16 *)g, (const _Float16 *)x, (_Float16 *)u, zp, (int)N, (int)K,            \
+                       (int)((N + 63) / 64)};                                                                  \
             ka.p[1] = ka.p[0]; ka.p[2] = ka.p[0];                                                              \
-            ka.x = (const _Float16 *)x; ka.ldx = ldx; ka.zp = zp; ka.T = (int)T; ka.K = (int)K;                \
+            ka.ldx = ldx; ka.T = (int)T;                                                                       \
             ob_launch_skinny<PARTIAL, RT_>(ka, ka.p[0].tile_end, s);                                           \
         } while (0)
         if (skinny && T <= 16) OB_SKINNY_GO(1);
@@ -541,6 +542,13 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ob_launch_mm16<false>(p.weight, p.ldw_bytes, xin, K, p.input_factor, p.weight_scale, uout, nullptr, B, K, N, s);
         return ob_launch_status("decode_step_batched(gemm)");
     };
+    // split-K for down_proj needs two fp32 [B, H] scratch rows: u_gate / u_up ([B, I] fp16) are free by then
+    float *zs0 = (float *)st->u_gate, *zs1 = (float *)st->u_up;
+    static const int splitk_env = getenv("OB_BATCH_SPLITK") ? atoi(getenv("OB_BATCH_SPLITK")) : 1;
+    bool splitk_down = splitk_env && (int64_t)I * 2 >= (int64_t)H * 4 && I % 256 == 0 && H % 8 == 0;
+    for (int l = 0; splitk_down && l < m->n_layers; ++l)
+        splitk_down = ob_skinny_ok((const uint32_t *)m->layers[l].down.weight + (I / 2) / 32, m->layers[l].down.ldw_bytes, B, I / 2) &&
+                      ob_skinny_ok(m->layers[l].down.weight, m->layers[l].down.ldw_bytes, B, I / 2);
     struct P3 { const onebit_proj_t *p[3]; };
     struct U3 { void *u[3]; };
     struct N3 { int64_t n[3]; };
@@ -568,9 +576,10 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             const onebit_proj_t &p = *ps.p[j];
             if (i < np) tiles += (int)((p.N + 63) / 64);
             ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.input_factor,
-                       (const _Float16 *)p.weight_scale, (_Float16 *)us.u[j], (int)p.N, tiles};
+                       (const _Float16 *)p.weight_scale, (const _Float16 *)xin, (_Float16 *)us.u[j], nullptr, (int)p.N,
+                       (int)K, tiles};
         }
-        ka.x = (const _Float16 *)xin; ka.ldx = K; ka.zp = nullptr; ka.T = B; ka.K = (int)K;
+        ka.ldx = K; ka.T = B;
         if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
         else if (B <= 32) ob_launch_skinny<false, 2>(ka, tiles, s);
         else ob_launch_skinny<false, 4>(ka, tiles, s);
@@ -582,7 +591,9 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer in layer %d", l);
         // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm
         ObBNormArgs na = {};
-        na.embed = (const _Float16 *)m->embed; na.tokens = st->tokens; na.hres_in = hA; na.u_prev = (const _Float16 *)st->u_down;
+        na.embed = (const _Float16 *)m->embed; na.tokens = st->tokens; na.hres_in = hA;
+        if (splitk_down && l > 0) { na.u_prev = nullptr; na.z0 = zs0; na.z1 = zs1; na.g_prev = (const _Float16 *)m->layers[l - 1].down.weight_scale; }
+        else na.u_prev = (const _Float16 *)st->u_down;
         na.rms_w = (const _Float16 *)L.input_layernorm_w; na.hres_out = hB; na.x = (_Float16 *)st->x; na.H = H;
         na.rms_eps = m->rms_eps; na.ln_eps = m->ln_eps;
         if (l == 0) hipLaunchKernelGGL(ob_b_norm_kernel<true>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
@@ -605,6 +616,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
         // 5. residual + LayerNorm(u_o) + post-attention RMSNorm
         ObBNormArgs nb = na;
+        nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o; nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
         hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
@@ -613,11 +625,32 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps};
         hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
-        if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
+        // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges
+        //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
+        if (splitk_down) {
+            const onebit_proj_t &p = L.down;
+            if (!p.weight || !p.input_factor || !p.weight_scale || p.K != I || p.N != H || p.ldw_bytes % 16 != 0)
+                return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: projection down has an unexpected shape");
+            const int Kh = I / 2, tiles1 = (H + 63) / 64;
+            ObSkinnyArgs ka = {};
+            for (int i = 0; i < 3; ++i) {
+                const int j = i < 2 ? i : 1;
+                ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4),
+                           (const _Float16 *)p.input_factor + j * Kh, (const _Float16 *)p.weight_scale,
+                           (const _Float16 *)st->act + j * Kh, nullptr, j == 0 ? zs0 : zs1, H, Kh, tiles1 * (j + 1)};
+            }
+            ka.ldx = I; ka.T = B;
+            if (B <= 16) ob_launch_skinny<true, 1>(ka, 2 * tiles1, s);
+            else if (B <= 32) ob_launch_skinny<true, 2>(ka, 2 * tiles1, s);
+            else ob_launch_skinny<true, 4>(ka, 2 * tiles1, s);
+            if ((rc = ob_launch_status("decode_step_batched(down)"))) return rc;
+        } else if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
     }
     // final: residual + LayerNorm(u_down) + final RMSNorm -> x
     ObBNormArgs nf = {};
-    nf.hres_in = hA; nf.u_prev = (const _Float16 *)st->u_down; nf.rms_w = (const _Float16 *)m->final_norm_w; nf.hres_out = hB;
+    nf.hres_in = hA; nf.rms_w = (const _Float16 *)m->final_norm_w; nf.hres_out = hB;
+    if (splitk_down) { nf.u_prev = nullptr; nf.z0 = zs0; nf.z1 = zs1; nf.g_prev = (const _Float16 *)m->layers[m->n_layers - 1].down.weight_scale; }
+    else nf.u_prev = (const _Float16 *)st->u_down;
     nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
     hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nf);
     return ob_launch_status("decode_step_batched(final norm)");
