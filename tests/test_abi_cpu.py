@@ -52,6 +52,21 @@ def test_argument_errors_without_gpu():
     assert fwd(K=40, ldw=5) == -5         # generic shape without workspace
     assert fwd(fl=64) == E_FLAG
     assert fwd(T=0) == 0
+    # N-sharded LayerNorm halves and the batched step reject bad arguments before any launch
+    assert lib.onebit_row_stats(a, a, 2, 0, 0, None) == E_SHAPE
+    assert lib.onebit_row_stats(None, a, 2, 8, 0, None) == E_ARG
+    assert lib.onebit_row_stats(a, a, 0, 8, 0, None) == 0
+    assert lib.onebit_row_stats(a, a, 2, 8, 5, None) == E_DTYPE
+    assert lib.onebit_normalize_rows(a, None, a, None, a, 2, 8, 0, None) == E_ARG
+    assert lib.onebit_normalize_rows(a, a, a, None, a, -1, 8, 0, None) == E_ARG
+    assert lib.onebit_decode_step_batched(None, None, None) == E_ARG
+    from onebit_amd.engine import _BatchState, _Layer, _Model
+    layers = (_Layer * 1)()
+    m = _Model(1, 64, 128, 2, 2, 32, 16, 8, 1e-6, 1e-5, layers, a, a, a, a, a)
+    st = _BatchState(1, a, a, a, a, a, a, a, a, a, a, a, a, a, a)
+    lib.onebit_decode_step_batched.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_BatchState), ctypes.c_void_p]
+    assert lib.onebit_decode_step_batched(ctypes.byref(m), ctypes.byref(st), None) == E_SHAPE      # batch 1
+    assert b"batch" in lib.onebit_last_error()
     with pytest.raises(ValueError):
         _lib.check(E_SHAPE, "x")
     with pytest.raises(RuntimeError):
