@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 1
+#define ONEBIT_ABI_VERSION 2
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -159,7 +159,14 @@ typedef struct onebit_decode_state {
     void *logits;               /* fp16 [vocab]                                                */
     float *part_val;            /* fp32 [1024] argmax partials                                 */
     int32_t *part_idx;          /* int32 [1024]                                                */
+    /* long contexts: attention split over the positions (two launches per layer over head x split,
+     * deterministic last-arriver combine).  attn_splits <= 1 or attn_scratch == NULL: one workgroup
+     * per head reads the whole history (the fast form up to a few hundred tokens).                 */
+    int32_t attn_splits;        /* S, 2..16                                                    */
+    void *attn_scratch;         /* onebit_attn_scratch_bytes(model, S) bytes, zero-filled once */
 } onebit_decode_state_t;
+
+size_t onebit_attn_scratch_bytes(const onebit_model_t *model, int32_t splits);
 
 int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t *state, void *stream);
 

@@ -951,6 +951,229 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long contexts: the same attention split over the positions (one workgroup per head reads the whole
+// KV history at ~15 GB/s; at 2k tokens that is 70 us per layer).  Two launches over (head, split):
+//   scores kernel: LayerNorm(q, k) + RoPE of the new token (recomputed per workgroup, as above), KV
+//                  append by (leader head, split 0), scores of the split's positions -> scratch, and
+//                  the split's (max, sum of exp relative to that max);
+//   pv kernel:     global max and denominator from the split statistics (fp32; the denominator is
+//                  sum_s l_s * exp(m_s - max)), p = fp16(exp(score - max) / l) exactly as the single
+//                  kernel forms it, partial P.V of the split (fp32) -> scratch; the LAST workgroup of
+//                  a head to arrive (agent-scope counter) adds the partials in split order and
+//                  writes the fp16 output -- deterministic.
+// Scratch per head: scores [max_len] fp32 | stats [S][2] | partial o [S][128] | counter.
+// ---------------------------------------------------------------------------------------------
+struct ObAttnSplitArgs {
+    ObAttnArgs a;
+    float *scores;        // [H][max_len]
+    float *stats;         // [H][S][2]
+    float *part;          // [H][S][128]
+    int *counter;         // [H], zero before the first use; the combining workgroup resets it
+    int S, chunk;         // splits, positions per split
+};
+
+__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(const ObAttnSplitArgs B)
+{
+    const ObAttnArgs &A = B.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = A.D, H = A.H, Hkv = A.Hkv;
+    const int head = blockIdx.x, split = blockIdx.y, kvh = head / (H / Hkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *red = reinterpret_cast<float *>(smem);
+    _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);
+    _Float16 *k_s = q_s + 128;
+    float *sl = reinterpret_cast<float *>(k_s + 128);        // [chunk] this split's scores (second pass)
+    const int pos = *A.pos;
+    const int L = pos + 1;
+    const int p_lo = split * B.chunk, p_hi = min(L, p_lo + B.chunk);
+    if (p_lo >= L) return;                                   // empty split (uniform)
+    const int NQ = H * D, NK = Hkv * D;
+    const _Float16 *kbase = A.kcache + (int64_t)kvh * A.max_len * D;
+    const int ds = tid & 15, pg = tid >> 4;
+    const int dcl = 8 * ds < D ? 8 * ds : 0;
+    const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
+    const int half = D >> 1;
+    const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;
+    const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
+    const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
+    const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
+    const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
+    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
+    for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
+        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
+    }
+    float s[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
+    ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);
+    if (tid < 128) {
+        float qe = 0.f, ke = 0.f;
+        if (tid < D) {
+            float mq, rq, mk, rk, mv, rv;
+            ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
+            ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
+            ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
+            const float c = (float)cosh_, sn = (float)sinh_;
+            const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
+            const float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
+            const float ve = ob_ln_apply((float)uvh, mv, rv);
+            const float qr = tid < half ? -q1 : q1, kr = tid < half ? -k1 : k1;
+            qe = ob_round_h(ob_round_h(q0 * c) + ob_round_h(qr * sn));
+            ke = ob_round_h(ob_round_h(k0 * c) + ob_round_h(kr * sn));
+            if (split == 0 && head % (H / Hkv) == 0) {       // one workgroup per kv head appends to the cache
+                A.kcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ke;
+                A.vcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ve;
+            }
+        }
+        q_s[tid] = (_Float16)qe; k_s[tid] = (_Float16)ke;
+    }
+    __syncthreads();
+    const float inv_sqrt_d = __builtin_amdgcn_rsqf((float)D);
+    auto dot8 = [](const ob_half8 a, const ob_half8 b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const ob_half2 x = {a[2 * e], a[2 * e + 1]}, y = {b[2 * e], b[2 * e + 1]};
+            acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+        }
+        return acc;
+    };
+    const ob_half8 q8 = *reinterpret_cast<const ob_half8 *>(q_s + 8 * ds);
+    const ob_half8 kn8 = *reinterpret_cast<const ob_half8 *>(k_s + 8 * ds);
+    float *sc = B.scores + (int64_t)head * A.max_len;
+    float lmax = -INFINITY;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 128) {
+        ob_half8 k8[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                            // the block's four rows in flight together
+            k8[i] = *reinterpret_cast<const ob_half8 *>(kbase + (int64_t)min(p0 + pg + 32 * i, A.max_len - 1) * D + dcl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : k8[i]));
+            const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
+            if (p < p_hi) {
+                if (ds == 0) { sc[p] = sv; sl[p - p_lo] = sv; }
+                lmax = fmaxf(lmax, sv);
+            }
+        }
+    }
+    lmax = ob_rows_max(lmax);
+    if (lane == 0) red[96 + wave] = lmax;
+    __syncthreads();
+    float m;
+    {
+        const ob_float4 m0 = *reinterpret_cast<const ob_float4 *>(red + 96), m1 = *reinterpret_cast<const ob_float4 *>(red + 100);
+        m = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
+    }
+    float lsum = 0.f;                                          // LDS copy, written before the barrier above
+    for (int p0 = p_lo; p0 < p_hi; p0 += 128) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            if (p < p_hi) lsum += __expf(sl[p - p_lo] - m);
+        }
+    }
+    lsum = ob_rows_sum(lsum);
+    if (lane == 0) red[112 + wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        const ob_float4 l0 = *reinterpret_cast<const ob_float4 *>(red + 112), l1 = *reinterpret_cast<const ob_float4 *>(red + 116);
+        float *st = B.stats + ((int64_t)head * B.S + split) * 2;
+        st[0] = m;
+        st[1] = ((l0[0] + l0[1]) + (l0[2] + l0[3])) + ((l1[0] + l1[1]) + (l1[2] + l1[3]));
+    }
+}
+
+__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_pv_kernel(const ObAttnSplitArgs B)
+{
+    const ObAttnArgs &A = B.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = A.D, H = A.H, Hkv = A.Hkv;
+    const int head = blockIdx.x, split = blockIdx.y, kvh = head / (H / Hkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *po = reinterpret_cast<float *>(smem);             // [8 waves][128]
+    int *flag = reinterpret_cast<int *>(po + OB_ATTN_WAVES * 128);
+    const int pos = *A.pos;                                  // the position has NOT been advanced yet
+    const int L = pos + 1;
+    const int p_lo = split * B.chunk, p_hi = min(L, p_lo + B.chunk);
+    if (p_lo >= L) return;
+    const int nsplit = (L + B.chunk - 1) / B.chunk;          // splits that hold positions
+    const _Float16 *vbase = A.vcache + (int64_t)kvh * A.max_len * D;
+    const int ds = tid & 15, pg = tid >> 4;
+    const int dcl = 8 * ds < D ? 8 * ds : 0;
+    // global max and denominator from the split statistics (every thread, a few L2 reads)
+    const float *st = B.stats + (int64_t)head * B.S * 2;
+    ob_float2 ml[16];                                        // all splits' (max, sum) in one round trip (S <= 16)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ml[j] = *reinterpret_cast<const ob_float2 *>(st + 2 * min(j, nsplit - 1));
+    float gmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gmax = fmaxf(gmax, ml[j][0]);          // clamped duplicates do not change the maximum
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) l += j < nsplit ? ml[j][1] * __expf(ml[j][0] - gmax) : 0.f;
+    const float inv_l = 1.0f / l;
+    const float *sc = B.scores + (int64_t)head * A.max_len;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = p_lo; p0 < p_hi; p0 += 128) {
+        ob_half8 v8[4];
+        float pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = min(p0 + pg + 32 * i, A.max_len - 1);
+            v8[i] = *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + dcl);
+            pr[i] = sc[min(p, L - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + pg + 32 * i;
+            if (p < p_hi) {
+                const float w = ob_round_h(__expf(pr[i] - gmax) * inv_l);     // softmax in fp32, probability -> fp16 (:562)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += w * (float)v8[i][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ob_rows_sum(o[e]);
+    if (lane < 16) {
+        float *dst = po + wave * 128 + 8 * ds;
+        *reinterpret_cast<ob_float4 *>(dst) = (ob_float4){o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<ob_float4 *>(dst + 4) = (ob_float4){o[4], o[5], o[6], o[7]};
+    }
+    __syncthreads();
+    float *part = B.part + ((int64_t)head * B.S) * 128;
+    if (tid < 128) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < OB_ATTN_WAVES; ++w) acc += po[w * 128 + tid];
+        part[split * 128 + tid] = acc;
+    }
+    __syncthreads();                                          // the workgroup's stores are ordered before ...
+    if (tid == 0) {                                           // ... ONE agent-scope release / acquire (L2 write-back, invalidate)
+        const int prev = __hip_atomic_fetch_add(B.counter + head, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = prev == nsplit - 1;
+        if (prev == nsplit - 1) __hip_atomic_store(B.counter + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (tid < D) {                                            // partials are read past the caches (agent-scope loads)
+        float v[16];                                           // all partials in flight together, then a fixed-order sum
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            v[j] = __hip_atomic_load(part + min(j, nsplit - 1) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += j < nsplit ? v[j] : 0.f;
+        A.out[head * D + tid] = (_Float16)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Final norm + fp16 lm_head GEMV + per-workgroup argmax (modeling_bitllama.py:1321,1610-1611;
 // generation/utils.py:2540).  Persistent grid, one row per wave iteration.
 // ---------------------------------------------------------------------------------------------

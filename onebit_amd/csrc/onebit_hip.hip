@@ -515,6 +515,12 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
     return ob_launch_dec_gemv(a, s);
 }
 
+extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
+{
+    if (!m || S < 2 || m->n_heads <= 0 || m->max_len <= 0) return 0;
+    return (size_t)m->n_heads * ((size_t)m->max_len * 4 + (size_t)S * 2 * 4 + (size_t)S * 128 * 4 + 4) + 64;
+}
+
 extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
 {
     if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
@@ -726,10 +732,28 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
-        const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
-        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
-        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
-        if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
+        if (st->attn_splits > 1 && st->attn_scratch) {
+            const int S = st->attn_splits;
+            if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);
+            ObAttnSplitArgs sp = {};
+            sp.a = at; sp.S = S; sp.chunk = ((m->max_len + S - 1) / S + 31) & ~31;
+            char *base = (char *)st->attn_scratch;
+            sp.scores = (float *)base;                      base += (size_t)m->n_heads * m->max_len * 4;
+            sp.stats = (float *)base;                       base += (size_t)m->n_heads * S * 2 * 4;
+            sp.part = (float *)base;                        base += (size_t)m->n_heads * S * 128 * 4;
+            sp.counter = (int *)base;
+            const size_t lds_a = 512 + 2 * 128 * 2 + (size_t)sp.chunk * 4, lds_b = (size_t)OB_ATTN_WAVES * 128 * 4 + 16;
+            if (lds_a > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for %d attention splits", m->max_len, S);
+            hipLaunchKernelGGL(ob_dec_attn_scores_kernel, dim3(m->n_heads, S), dim3(OB_ATTN_THREADS), lds_a, s, sp);
+            if ((rc = ob_launch_status("decode_step(attn scores)"))) return rc;
+            hipLaunchKernelGGL(ob_dec_attn_pv_kernel, dim3(m->n_heads, S), dim3(OB_ATTN_THREADS), lds_b, s, sp);
+            if ((rc = ob_launch_status("decode_step(attn pv)"))) return rc;
+        } else {
+            const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
+            if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
+            hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+            if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
+        }
         // K3: o_proj
         ObGemvArgs o = {};
         o.nproj = 1; o.K = (int)L.o.K; o.prologue = OB_P_PLAIN; o.xin = (const _Float16 *)st->attn_out;

@@ -46,7 +46,7 @@ class _State(ctypes.Structure):
     _fields_ = [("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
-                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp)]
+                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp)]
 
 
 class _BatchState(ctypes.Structure):
@@ -98,7 +98,10 @@ def _proj(m: BitLinearInf) -> _Proj:
 
 
 class DecodeEngine:
-    def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True):
+    def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True,
+                 long_context_from: int = 384, attn_splits: int = 8):
+        """``long_context_from``: position from which a step uses the split-KV attention graph (two
+        launches per layer over head x split); below it one workgroup per head is faster.  0 disables."""
         cfg = model.config
         p = model.lm_head.weight
         if not p.is_cuda:
@@ -145,11 +148,13 @@ class DecodeEngine:
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
-                             b["part_val"].data_ptr(), b["part_idx"].data_ptr())
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None)
         self.lib.onebit_decode_step.restype = ctypes.c_int
         self.lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), _vp]
-        self.graph = None
+        self.graph = self.graph_long = None
         self._prompt_len = 0
+        self._steps = 0                     # host-side count of tokens in the cache (chooses the graph)
+        self._long_from = int(long_context_from) if long_context_from and self.max_len > long_context_from else 0
         self._launch()                      # warm-up: validates arguments, sets function attributes
         torch.cuda.synchronize(dev)
         if use_graph:
@@ -157,12 +162,29 @@ class DecodeEngine:
             with torch.cuda.graph(g):
                 self._launch()
             self.graph = g
+        if self._long_from:
+            S = max(2, min(int(attn_splits), 16, self.max_len // 128))
+            self.lib.onebit_attn_scratch_bytes.restype = ctypes.c_size_t
+            self.lib.onebit_attn_scratch_bytes.argtypes = [ctypes.POINTER(_Model), ctypes.c_int]
+            nbytes = self.lib.onebit_attn_scratch_bytes(ctypes.byref(self._model), S)
+            self._scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            self._state_long = _State.from_buffer_copy(self._state)
+            self._state_long.attn_splits = S
+            self._state_long.attn_scratch = self._scratch.data_ptr()
+            self.pos.zero_()
+            self._launch(long=True)
+            torch.cuda.synchronize(dev)
+            if use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch(long=True)
+                self.graph_long = g
         self.pos.zero_()
         self.token.zero_()
 
-    def _launch(self):
+    def _launch(self, long: bool = False):
         with torch.cuda.device(self.dev):
-            rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(self._state),
+            rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(self._state_long if long else self._state),
                                              torch.cuda.current_stream(self.dev).cuda_stream)
         _lib.check(rc, "onebit_decode_step")
 
@@ -180,20 +202,25 @@ class DecodeEngine:
         self.token.copy_(logits[0, -1].argmax().to(torch.int32).reshape(1))
         self.pos.fill_(S)
         self._prompt_len = S
+        self._steps = S
         self.first_token = int(self.token.item())
         return logits
 
     def set_state(self, token: int, pos: int):
         self.token.fill_(int(token))
         self.pos.fill_(int(pos))
+        self._steps = int(pos)
 
     def step(self):
         """Decode one token (asynchronous): consumes the device-side token, appends to the KV cache,
         leaves the next greedy token on the device."""
-        if self.graph is not None:
-            self.graph.replay()
+        long = bool(self._long_from) and self._steps >= self._long_from
+        g = self.graph_long if long else self.graph
+        if g is not None:
+            g.replay()
         else:
-            self._launch()
+            self._launch(long=long)
+        self._steps += 1
 
     def logits(self) -> torch.Tensor:
         """fp32 logits of the last step (the reference returns logits.float())."""

@@ -181,15 +181,21 @@ def test_fused_gemv_each_prologue(H, I):
     check(od, _ref_u(mlp.down_proj, act), "swiglu")
 
 
-@pytest.mark.parametrize("cfgkw,prompt_len,steps", [
+@pytest.mark.parametrize("cfgkw,prompt_len,steps,engine_kw", [
     # grouped-query attention: 8 query heads share 2 kv heads
     (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
-          num_key_value_heads=2, max_position_embeddings=64), 7, 10),
+          num_key_value_heads=2, max_position_embeddings=64), 7, 10, dict(long_context_from=0)),
     # long context: > 256 cached positions (keys beyond the register-preloaded window, values beyond 128)
     (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
-          max_position_embeddings=512), 300, 6),
+          max_position_embeddings=512), 300, 6, dict(long_context_from=0)),
+    # the same through the split-KV attention (4 splits of 128 positions: 3 hold data at 300 tokens)
+    (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+          max_position_embeddings=512), 300, 6, dict(long_context_from=64, attn_splits=4)),
+    # split-KV with grouped-query attention and a position crossing a split boundary (chunk = 32)
+    (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+          num_key_value_heads=2, max_position_embeddings=256), 60, 10, dict(long_context_from=16, attn_splits=8)),
 ])
-def test_engine_attention_variants(cfgkw, prompt_len, steps):
+def test_engine_attention_variants(cfgkw, prompt_len, steps, engine_kw):
     from onebit_amd.engine import DecodeEngine
     from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
     dev = torch.device("cuda:0")
@@ -206,7 +212,8 @@ def test_engine_attention_variants(cfgkw, prompt_len, steps):
         ref_logits.append(lg[0, -1].cpu().numpy())
         tok = lg[:, -1].argmax(-1, keepdim=True)
         ref_toks.append(int(tok))
-    eng = DecodeEngine(model, max_len=cfg.max_position_embeddings)
+    eng = DecodeEngine(model, max_len=cfg.max_position_embeddings, **engine_kw)
+    assert (eng.graph_long is not None) == bool(engine_kw.get("long_context_from"))
     eng.prefill(ids)
     assert eng.first_token == ref_toks[0]
     ref = np.stack(ref_logits)
