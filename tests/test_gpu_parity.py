@@ -335,3 +335,26 @@ def test_n_sharded_rows_match_full_forward():
     for r in range(2):
         sh = shard_n(m.weight.data, m.input_factor.data, m.weight_scale.data, None, r, 2)
         assert torch.equal(hip_rows_u(sh, x), u[:, sh.n0:sh.n1])
+
+
+def test_forward_shape_sweep_hits_every_kernel_route(dev, coracle):
+    """T x K x N sweep across the dispatch boundaries of onebit_linear_forward (decode GEMV at T = 1,
+    skinny kernel 2..64 with 16/32/64-token tiles, 64-row GEMM tiles for unaligned rows, 128 x 128
+    prefill tile, ragged last tiles in every dimension) against the oracle, fp16."""
+    rng = np.random.default_rng(123)
+    shapes = []
+    for T in (1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 129):
+        for (K, N) in ((512, 64), (1024, 80), (640, 200), (96, 48)):      # 96: K % 128 != 0 -> no skinny / aligned GEMV
+            shapes.append((T, K, N))
+    shapes += [(5, 2048, 24), (40, 1536, 136), (130, 256, 264), (1, 2560, 72)]
+    for (T, K, N) in shapes:
+        packed = rng.integers(0, 256, (N, K // 8), dtype=np.uint8).view(np.int8)
+        h = (0.1 * (0.5 + rng.random(K)) * np.where(rng.random(K) < 0.1, -1, 1)).astype(np.float16)
+        g = (0.1 * (0.5 + rng.random(N)) * np.where(rng.random(N) < 0.1, -1, 1)).astype(np.float16)
+        x = rng.standard_normal((T, K)).astype(np.float16)
+        y_ref, u_ref = coracle.forward_f16(packed, x, h, g, None, return_pre_ln=True)
+        m = _make_layer(K, N, torch.float16, dev, packed, h, g)
+        y = m(_t(x, dev)).cpu().numpy()
+        m.layernorm = torch.nn.Identity()
+        u = m(_t(x, dev)).cpu().numpy()
+        _check_f16(y, u, y_ref, u_ref, (T, K, N))
