@@ -563,6 +563,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         //     and one wave's VALU work overlaps another wave's MFMAs on the same SIMD.
         ob_half8 ah[NPROJ][KV];
         int e_w[NPROJ];
+        bool nonfinite[NPROJ];
 #pragma unroll
         for (int v = 0; v < KV; ++v)
             if (!valid[v]) xh[v] = (ob_half8)(_Float16)0;          // zero padding up to Kpad
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
             const uint32_t m = ob_wave_max_u32(max((uint32_t)mx[0], (uint32_t)mx[1]));
             e_w[p] = (int)max(m >> 10, 1u) - 15;        // |a| < 2^(e+1) for every element of this wave
+            nonfinite[p] = m >= 0x7c00u;                // an Inf / NaN activation: fixed point cannot carry it
         }
         OB_STAMP(3);
         // this lane's two bit positions j = 2jp + s: compensation 2^(7-j) (j < 7) or -1 (j = 7) folded
@@ -688,7 +690,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             const float dscale = __uint_as_float((uint32_t)(127 + 8 * (lane & 3)) << 23);
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                const float f = dscale * inv_scale[j % NPROJ];
+                // a non-finite activation makes the whole output row NaN, as it does in the reference's GEMM
+                const float f = nonfinite[j % NPROJ] ? __builtin_nanf("") : dscale * inv_scale[j % NPROJ];
                 float *dst = lds_red + (((j * OB_DEC_WAVES + wave) * 16 + 4 * gq) << 2) + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[4 * r] = (float)(sdig[j % NPROJ] - 2 * acc[j][r]) * f;

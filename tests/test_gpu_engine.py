@@ -240,3 +240,26 @@ def test_engine_is_deterministic_across_graphs_and_runs():
         runs.append(eng.generate(ids, 200)[0].tolist())
     assert runs[0] == runs[1]
     assert len(set(runs[0][40:])) > 8            # not a degenerate constant stream
+
+
+def test_fused_gemv_propagates_non_finite_activations():
+    """The integer sign path quantises the activations; an Inf / NaN among them must still poison the
+    outputs the way it does in the reference's fp16 GEMM (every output row sums over all of K)."""
+    from onebit_amd import BitLinearInf
+    from onebit_amd.engine import PRO_PLAIN, fused_gemv
+    dev = torch.device("cuda:0")
+    K, N = 8192, 256                                   # two 4096-chunks: the integer path is taken
+    g = torch.Generator().manual_seed(0)
+    m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
+    m.weight.data = torch.randint(0, 256, (N, K // 8), generator=g, dtype=torch.uint8).view(torch.int8).to(dev)
+    m.input_factor.data = (0.1 * (0.5 + torch.rand(K, generator=g))).half().to(dev)
+    m.weight_scale.data = (0.1 * (0.5 + torch.rand(N, generator=g))).half().to(dev)
+    x = torch.randn(K, generator=g).half().to(dev)
+    out = torch.empty(N, dtype=torch.float16, device=dev)
+    fused_gemv([m], [out], PRO_PLAIN, xin=x)
+    assert torch.isfinite(out).all()
+    for bad in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb[5000] = bad
+        fused_gemv([m], [out], PRO_PLAIN, xin=xb)
+        assert torch.isnan(out).all()
