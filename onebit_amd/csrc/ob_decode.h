@@ -182,72 +182,26 @@ __device__ __forceinline__ ob_u32x4 ob_dec_load_w(const uint32_t *w, int N, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Integer sign path (MATH == 1).  Per projection the activation vector a = fp16(x*h) is quantised
-// once per workgroup to fixed point relative to its largest element, q = a * 2^(22 - e)
-// (|q| < 2^23; exact for every element within 12 binades of the maximum, otherwise rounded at
-// 2^-23 of the maximum -- below fp32 accumulation noise), and split into 4 signed int8 digits.
+// Integer sign path (MATH == 1).  Each wave quantises the elements of a = fp16(x*h) it owns (its
+// 512-weight chunks) to fixed point relative to their largest one, q = a * 2^(22 - e) (|q| < 2^23;
+// exact for every element within 12 binades of that maximum, otherwise rounded at 2^-23 of it --
+// below fp32 accumulation noise), and splits q into 4 signed int8 digits.
 // The A operand of v_mfma_i32_16x16x64_i8 is then simply  w & (0x01010101 << j)  : byte i of that
 // dword is bit (8i + j) of the packed word times 2^j, i.e. ONE v_and per 4 weights.  The factor
 // 2^j (and the sign of 0x80 for j = 7) is folded into the activation side: element k with bit
 // position j = k % 8 is stored as m' = q * 2^(7-j) (j < 7) or -q (j = 7), so every product is
-// 128 * b * q.  With B = sum over set bits and S = sum over all (an all-ones "row" on the same
-// MFMA path), z = (S - 2B) / (128 * 2^(22-e)) exactly: integer accumulation, no rounding, no
-// dependence on summation order.  The 4 digits of an element sit in one dword [d0 d1 d2 d3]; the
-// MFMA B operand wants 4 consecutive k of ONE digit per dword, so each quad of lanes does a 4x4
-// byte transpose (2 DPP moves + 2 v_perm per dword) before the LDS write.
+// 128 * b * q.  With B = sum over set bits (int32 per digit) and S = sum over all elements
+// (v_dot4 per lane + an exact cross-lane reduction), S_c - 2 B_c is exact per digit c; one
+// conversion to fp32 per (wave, row, digit), scaled by exact powers of two, a fixed-order sum.
+// The 4 digits of an element sit in one dword [d0 d1 d2 d3]; the MFMA B operand wants the same
+// digit of 4 elements per dword -- with the strided element ownership below that is a
+// thread-local 4x4 byte transpose (8 v_perm per 4 elements).
 //
 // LDS image per projection: [Q = k/32][digit c][32 bytes], the 32 bytes = dwords j = 0..7, dword j
 // = digit c of k = 32Q + 8i + j for i = 0..3.  MFMA step (q, jh) of chunk ch, lane (g, c): 16 bytes
 // at ((ch*16 + g*4 + q) * 4 + (c & 3)) * 32 + jh * 16.  Lanes with c >= 4 replicate digit c & 3
-// (their result columns are simply not used).
+// (their result columns are simply not used).  A wave reads back only what it wrote itself.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ob_quad_transpose(uint32_t w, uint32_t selA, uint32_t selB)
-{
-    const uint32_t p1 = __builtin_amdgcn_update_dpp(0u, w, 0x4E, 0xF, 0xF, false);     // lane ^ 2
-    const uint32_t n1 = __builtin_amdgcn_perm(p1, w, selA);
-    const uint32_t p2 = __builtin_amdgcn_update_dpp(0u, n1, 0xB1, 0xF, 0xF, false);    // lane ^ 1
-    return __builtin_amdgcn_perm(p2, n1, selB);
-}
-
-template <int NV, int NW>
-__device__ __forceinline__ void ob_block_max_n(float (&v)[NV], float *red)
-{
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = ob_wave_max(v[i]);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) red[i * 16 + wave] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        float s = -INFINITY;
-#pragma unroll
-        for (int w4 = 0; w4 < NW; w4 += 4) {
-            const ob_float4 a = *reinterpret_cast<const ob_float4 *>(red + i * 16 + w4);
-            s = fmaxf(s, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
-        }
-        v[i] = s;
-    }
-}
-
-// 8 MFMAs for one 512-weight chunk of a 16-row tile on the integer path.
-__device__ __forceinline__ void ob_dec_chunk_i8(const ob_u32x4 w4, const char *b_base, ob_i32x4 &acc)
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t w = w4[q];
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-            const ob_i32x4 bv = *reinterpret_cast<const ob_i32x4 *>(b_base + q * 128 + jh * 16);
-            ob_i32x4 av;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc, 0, 0, 0);
-        }
-    }
-}
 
 // Element ownership in the GEMV prologue.  Contiguous (fp16 path): the thread holds 8 consecutive
 // elements.  Strided (integer path): lane (Q = lane >> 2, jp = lane & 3) of the wave that owns a
