@@ -97,6 +97,31 @@ def _proj(m: BitLinearInf) -> _Proj:
                  m.out_features, m.in_features, w.stride(0))
 
 
+def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int):
+    """ctypes image of ``onebit_model_t`` for ``model`` with per-layer (k, v) cache tensors; returns
+    (struct, objects that must stay alive as long as the struct is used)."""
+    cfg = model.config
+    p = model.lm_head.weight
+    dev, f16 = p.device, torch.float16
+    cos, sin = model._rope_tables(dev, f16)
+    cos, sin = cos.contiguous(), sin.contiguous()
+    layers = (_Layer * cfg.num_hidden_layers)()
+    for i, (layer, (kc, vc)) in enumerate(zip(model.model.layers, caches)):
+        a, mlp = layer.self_attn, layer.mlp
+        for w in (layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
+            if w.dtype != f16:
+                raise ValueError("the decode steps need fp16 RMSNorm weights")
+        layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
+                           _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
+                           layer.input_layernorm.weight.data_ptr(),
+                           layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
+    m = _Model(cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
+               cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size, max_len, cfg.rms_norm_eps, 1e-5, layers,
+               model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
+               model.lm_head.weight.data_ptr(), cos.data_ptr(), sin.data_ptr())
+    return m, [layers, cos, sin]
+
+
 class DecodeEngine:
     def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True,
                  long_context_from: int = 384, attn_splits: int = 8):
@@ -118,23 +143,7 @@ class DecodeEngine:
         dev, f16 = self.dev, torch.float16
         H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
         self.cache = KVCache(cfg, 1, self.max_len, dev, f16)
-        cos, sin = model._rope_tables(dev, f16)
-        self._keep = [cos.contiguous(), sin.contiguous()]
-        layers = (_Layer * cfg.num_hidden_layers)()
-        for i, (layer, (kc, vc)) in enumerate(zip(model.model.layers, self.cache.layers)):
-            a, mlp = layer.self_attn, layer.mlp
-            layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
-                               _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
-                               layer.input_layernorm.weight.data_ptr(),
-                               layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
-            for w in (layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
-                if w.dtype != f16:
-                    raise ValueError("DecodeEngine needs fp16 RMSNorm weights")
-        self._layers = layers
-        self._model = _Model(cfg.num_hidden_layers, H, I, cfg.num_attention_heads, cfg.num_key_value_heads, D,
-                             cfg.vocab_size, self.max_len, cfg.rms_norm_eps, 1e-5, layers,
-                             model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
-                             model.lm_head.weight.data_ptr(), self._keep[0].data_ptr(), self._keep[1].data_ptr())
+        self._model, self._keep = _model_struct(model, self.cache.layers, self.max_len)
         z = lambda n, dt=f16: torch.zeros(n, dtype=dt, device=dev)
         self.token = z(1, torch.int32)
         self.pos = z(1, torch.int32)
@@ -258,23 +267,11 @@ class BatchedDecodeStep:
         self.lib = _lib.load()
         dev, f16 = self.dev, torch.float16
         H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
-        cos, sin = model._rope_tables(dev, f16)
-        self._keep = [cos.contiguous(), sin.contiguous()]
-        layers = (_Layer * cfg.num_hidden_layers)()
         shape = (batch, cfg.num_key_value_heads, max_len, D)
-        for i, (layer, (kc, vc)) in enumerate(zip(model.model.layers, caches)):
+        for i, (kc, vc) in enumerate(caches):
             if tuple(kc.shape) != shape or tuple(vc.shape) != shape or not kc.is_contiguous() or not vc.is_contiguous():
                 raise ValueError(f"cache {i} must be contiguous {shape}")
-            a, mlp = layer.self_attn, layer.mlp
-            layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
-                               _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
-                               layer.input_layernorm.weight.data_ptr(),
-                               layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
-        self._layers = layers
-        self._model = _Model(cfg.num_hidden_layers, H, I, cfg.num_attention_heads, cfg.num_key_value_heads, D,
-                             cfg.vocab_size, max_len, cfg.rms_norm_eps, 1e-5, layers,
-                             model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
-                             model.lm_head.weight.data_ptr(), self._keep[0].data_ptr(), self._keep[1].data_ptr())
+        self._model, self._keep = _model_struct(model, caches, max_len)
         z = lambda *n: torch.zeros(*n, dtype=f16, device=dev)
         Hq, Hkv = cfg.num_attention_heads * D, cfg.num_key_value_heads * D
         self.tokens = torch.zeros(batch, dtype=torch.int32, device=dev)
