@@ -1,20 +1,20 @@
 // Skinny 1-bit GEMM for gfx950, 2 <= T <= 64 tokens (short prompts, batched decode):
 // z[t][n] = sum_k s[n][k] * fp16(x[t][k] * h[k]) on v_mfma_f32_16x16x32_f16, fp32 accumulate.
 //
-// At these sizes the packed matrix (N*K/8 bytes from HBM) is the traffic and latency is the enemy,
-// so the kernel is built from few, large, fully prefetched phases instead of many small K steps:
-//   * workgroup = 8 waves = 64 rows x all T tokens (RT groups of 16) x all of K: wave (wr, kh) owns
-//     the 16-row tile wr and the k-half kh of every 512-weight chunk (words 2kh, 2kh+1 of the lane's
-//     four), so two waves per SIMD overlap sign expansion, MFMA and LDS reads; the two halves meet
-//     in LDS at the end.  grid = N / 64 workgroups, one per CU;
-//   * K advances in phases of PK = 1024 / RT (RT = 4: 512) elements: the activation
-//     tile of a phase (16*RT tokens x PK) is loaded coalesced into registers one phase ahead
-//     (4-8 x 16-byte loads per thread, every thread owns ONE k-piece of its tokens, so one h load
-//     serves them), multiplied by h (the fp16 rounding of bitnet.py:113) and written to padded LDS
-//     rows; the weights of a phase are PK/512 dwordx4 per lane, also one phase ahead;
-//   * per 512-weight chunk a wave expands its 16 rows' signs once and feeds RT token groups;
-//     with fewer than 4 token groups the k-blocks rotate over 4 / RT accumulators per group so
-//     that consecutive MFMAs never wait on each other.
+// At these sizes the packed matrix (N*K/8 bytes from HBM) is the traffic, and what a naive tiling
+// drowns in is LDS reads: an activation fragment that feeds one MFMA per read makes the LDS pipe
+// (128 B/clk) the bottleneck long before HBM or the matrix pipe.  So:
+//   * workgroup = 8 waves = 64 rows x all T tokens (RT groups of 16) x all of K; grid = N / 64;
+//   * the 16 k-blocks (32 weights each) of every 512-weight chunk are dealt to the 8 waves (wave w:
+//     packed word q = w >> 1, half hf = w & 1, two blocks s2 = 0, 1), and each wave covers ALL FOUR
+//     16-row tiles for its blocks: an activation fragment is read from LDS exactly once per
+//     workgroup and feeds 4 MFMAs (4 * RT independent accumulators per wave); the 8 partial
+//     accumulators meet in LDS at the end;
+//   * K advances in phases of PK = 512 elements, double-buffered: the
+//     activation tile of a phase (16*RT tokens x PK; every thread owns ONE k-piece of its tokens, so
+//     one h load serves them) and the packed rows of the phase (64 rows x PK/8 bytes: 4-8 KB, one
+//     coalesced 16-byte load per thread) are loaded one phase ahead into registers, the activations
+//     multiplied by h (the fp16 rounding of bitnet.py:113), and both written to padded LDS rows.
 // Same register-level conventions as ob_gemm.h / ob_decode.h: weights = A operand (row = lane & 15,
 // k-group = lane >> 4), activations = B operand (column = token).
 #pragma once
@@ -38,10 +38,10 @@ struct ObSkinnyArgs {
     int T;
 };
 
-// tokens x k elements of one phase: 16 x 1024 / 32 x 512 (66 KB of LDS: two workgroups per CU, so a
-// grid of up to 512 tiles is resident at once and one workgroup's loads hide behind the other's
-// MFMAs) or 64 x 512 (133 KB, one workgroup per CU)
-#define OB_SKINNY_PKT(RT_) ((RT_) == 4 ? 2048 : 1024)
+// tokens x k elements of one phase: 16*RT x 512 (42 / 75 / 142 KB of LDS with the packed rows: three,
+// two or one workgroup per CU)
+#define OB_SKINNY_PKT(RT_) (512 * (RT_))
+#define OB_SKINNY_LDS(RT_) ((size_t)2 * 16 * (RT_) * (512 + 8) * 2 + (size_t)2 * 64 * (512 / 32 + 1) * 4)
 
 template <bool PARTIAL, int RT>
 __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A)
@@ -56,60 +56,56 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     const int T = A.T, K = P.K, N = P.N;
     const int tile0 = pi == 0 ? 0 : (pi == 1 ? A.p[0].tile_end : A.p[1].tile_end);
     constexpr int PK = OB_SKINNY_PKT(RT) / RT;  // k elements per phase
-    constexpr int CPP = PK / 512;               // 512-weight chunks (one dwordx4 per lane) per phase
+    constexpr int CPP = PK / 512;               // 512-weight chunks per phase
     constexpr int TT = 16 * RT;                 // tokens of the tile
-    constexpr int PITCH = PK + 8;               // halves per LDS row (16-byte pad: rows shift by 4 banks)
-    constexpr int NS = 4 / RT;                  // accumulators per token group
-    constexpr int PPR = PK / 8;                 // 16-byte pieces per token row and phase
+    constexpr int PITCH = PK + 8;               // halves per activation row (16-byte pad: rows shift by 4 banks)
+    constexpr int WP = PK / 32 + 1;             // dwords per packed row in LDS (+1: the 16 rows of a tile hit 16 banks)
+    constexpr int PPR = PK / 8;                 // 16-byte activation pieces per token row and phase
+    constexpr int WPR = PK / 128;               // 16-byte packed pieces per weight row and phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16 *As = reinterpret_cast<_Float16 *>(smem);          // [2][TT][PITCH]
+    _Float16 *As = reinterpret_cast<_Float16 *>(smem);                                   // [2][TT][PITCH]
+    uint32_t *Ws = reinterpret_cast<uint32_t *>(smem + (size_t)2 * TT * PITCH * 2);      // [2][64][WP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, gq = lane >> 4;
-    const int wr = wave & 3, kh = wave >> 2;
-    const int n0 = ((int)blockIdx.x - tile0) * 64 + wr * 16;
+    const int wq = wave >> 1, hf = wave & 1;    // this wave's packed word and half of every chunk
+    const int n0 = ((int)blockIdx.x - tile0) * 64;
     const int nph = (K + PK - 1) / PK;
     const int nwords = K >> 5;
 
-    // staging: thread owns k-piece `kp` of token rows tok0 + (512 / PPR) * i
+    // staging: thread owns activation k-piece `kp` of token rows tok0 + TSTEP * i, and (threads below
+    // 64 * WPR) one 16-byte piece of one packed row
     const int kp = tid % PPR, tok0 = tid / PPR;
-    constexpr int TSTEP = 512 / PPR;            // 2, 4, 8 for RT = 1, 2, 4
-    constexpr int NSTG = TT / TSTEP;            // 4 (RT = 1, 2) or 8 (RT = 4) loads per thread and phase
+    constexpr int TSTEP = 512 / PPR;            // 8 token rows per pass of the 512 threads
+    constexpr int NSTG = TT / TSTEP;            // 2, 4, 8 loads per thread and phase for RT = 1, 2, 4
     const _Float16 *xrow[NSTG];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
-    const uint32_t *wrow = W + (int64_t)min(n0 + r, N - 1) * ldw_words;
+    const bool wload = tid < 64 * WPR;
+    const int wrow_i = wload ? tid / WPR : 0, wpc = wload ? tid % WPR : 0;
+    const uint32_t *wsrc = W + (int64_t)min(n0 + wrow_i, N - 1) * ldw_words;
 
-    ob_float4 acc[RT][NS];
+    ob_float4 acc[4][RT];
 #pragma unroll
-    for (int a = 0; a < RT; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NS; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < RT; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
 
-    // raw loads only (clamped addresses); masks are applied after the phase's MFMA block is issued
+    // raw loads only (clamped addresses); masks are applied when the registers are consumed
     ob_half8 xs[NSTG], hs;
-    ob_u32x2 wcur[CPP], wnext[CPP];
-    bool kv_ld = true;
-    auto load_x = [&](int ph) {
+    ob_u32x4 wv = {0u, 0u, 0u, 0u};
+    bool kv_ld = true, wv_ld = true;
+    auto load_phase = [&](int ph) {
         const int k = ph * PK + kp * 8;
         kv_ld = k < K;
         const int kc = kv_ld ? k : 0;
         hs = *reinterpret_cast<const ob_half8 *>(h + kc);
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) xs[i] = *reinterpret_cast<const ob_half8 *>(xrow[i] + kc);
+        const int word = ph * (PK / 32) + wpc * 4;
+        wv_ld = word < nwords;
+        if (wload) wv = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(wsrc + min(word, nwords - 4)));
     };
-    auto load_w = [&](int ph, ob_u32x2 (&w)[CPP]) {
-#pragma unroll
-        for (int c = 0; c < CPP; ++c) {
-            const int word = (ph * CPP + c) * 16 + gq * 4;
-            w[c] = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x2 *>(wrow + min(word, nwords - 4) + 2 * kh));
-        }
-    };
-    auto mask_w = [&](int ph, ob_u32x2 (&w)[CPP]) {
-#pragma unroll
-        for (int c = 0; c < CPP; ++c)
-            if ((ph * CPP + c) * 16 + gq * 4 >= nwords) w[c] = (ob_u32x2){0u, 0u};
-    };
-    auto store_x = [&](int buf) {
+    auto store_phase = [&](int buf) {
         _Float16 *dst = As + (size_t)buf * TT * PITCH + kp * 8;
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) {
@@ -117,81 +113,69 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
             if (!kv_ld) a = (ob_half8)(_Float16)0;
             *reinterpret_cast<ob_half8 *>(dst + (size_t)(tok0 + TSTEP * i) * PITCH) = a;
         }
+        if (wload) {
+            uint32_t *wd = Ws + ((size_t)buf * 64 + wrow_i) * WP + wpc * 4;
+            const ob_u32x4 w = wv_ld ? wv : (ob_u32x4){0u, 0u, 0u, 0u};
+            wd[0] = w[0]; wd[1] = w[1]; wd[2] = w[2]; wd[3] = w[3];                    // WP is odd: dword stores
+        }
     };
 
-    load_x(0);
-    load_w(0, wcur);
-    store_x(0);
-    mask_w(0, wcur);
+    load_phase(0);
+    store_phase(0);
     __syncthreads();
 
     for (int ph = 0; ph < nph; ++ph) {
         const int cur = ph & 1;
         const bool more = ph + 1 < nph;
-        if (more) {
-            load_x(ph + 1);
-            load_w(ph + 1, wnext);
-        }
+        if (more) load_phase(ph + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const _Float16 *Ab = As + (size_t)cur * TT * PITCH + (size_t)r * PITCH + gq * 128;
+        const _Float16 *Ab = As + (size_t)cur * TT * PITCH + (size_t)r * PITCH + gq * 128 + wq * 32 + hf * 16;
+        const uint32_t *Wb = Ws + ((size_t)cur * 64 + r) * WP + gq * 4 + wq;
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
+            uint32_t e[4][8];
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int q = 2 * kh + q2;          // this wave's words of the chunk
+            for (int rn = 0; rn < 4; ++rn)
+                ob_expand16((Wb[(size_t)rn * 16 * WP + c * 16] >> (16 * hf)) & 0xffffu, e[rn]);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    uint32_t e[8];
-                    ob_expand16((wcur[c][q2] >> (16 * hf)) & 0xffffu, e);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                ob_half8 bop[RT];
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        ob_u32x4 av = {e[4 * s2 + 0], e[4 * s2 + 1], e[4 * s2 + 2], e[4 * s2 + 3]};
-                        ob_half8 aop;
-                        __builtin_memcpy(&aop, &av, 16);
+                for (int rt = 0; rt < RT; ++rt)
+                    bop[rt] = *reinterpret_cast<const ob_half8 *>(Ab + (size_t)rt * 16 * PITCH + c * 512 + s2 * 8);
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            const ob_half8 bop = *reinterpret_cast<const ob_half8 *>(
-                                Ab + (size_t)rt * 16 * PITCH + c * 512 + q * 32 + (2 * hf + s2) * 8);
-                            acc[rt][(2 * hf + s2) % NS] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, bop, acc[rt][(2 * hf + s2) % NS], 0, 0, 0);
-                        }
-                    }
+                for (int rn = 0; rn < 4; ++rn) {
+                    ob_u32x4 av = {e[rn][4 * s2 + 0], e[rn][4 * s2 + 1], e[rn][4 * s2 + 2], e[rn][4 * s2 + 3]};
+                    ob_half8 aop;
+                    __builtin_memcpy(&aop, &av, 16);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rn][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, bop[rt], acc[rn][rt], 0, 0, 0);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            store_x(cur ^ 1);
-            mask_w(ph + 1, wnext);
-#pragma unroll
-            for (int c = 0; c < CPP; ++c) wcur[c] = wnext[c];
-        }
+        if (more) store_phase(cur ^ 1);
         __syncthreads();
     }
 
-    // the two k-halves meet in LDS (the activation buffers are free after the last barrier)
-    float *zr = reinterpret_cast<float *>(smem);                // [4 row tiles][RT][64 lanes][4]
-    if (kh == 1) {
+    // the 8 waves' partial accumulators meet in LDS (the staging buffers are free after the last barrier):
+    // [wave][rn][rt][lane] float4, then output slot (rn, rt, lane) is summed by one thread
+    ob_float4 *zr = reinterpret_cast<ob_float4 *>(smem);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            ob_float4 z = acc[rt][0];
+    for (int rn = 0; rn < 4; ++rn)
 #pragma unroll
-            for (int b = 1; b < NS; ++b) z += acc[rt][b];
-            *reinterpret_cast<ob_float4 *>(zr + ((size_t)(wr * RT + rt) * 64 + lane) * 4) = z;
-        }
-    }
+        for (int rt = 0; rt < RT; ++rt) zr[((wave * 4 + rn) * RT + rt) * 64 + lane] = acc[rn][rt];
     __syncthreads();
-    if (kh == 1) return;
-    // epilogue: lane holds rows n0 + 4*gq + i of token 16*rt + r
+    constexpr int NSLOT = 4 * RT * 64;
+    for (int slot = tid; slot < NSLOT; slot += 512) {
+        const int sl = slot & 63, rt = (slot >> 6) % RT, rn = (slot >> 6) / RT;
+        ob_float4 z = zr[((0 * 4 + rn) * RT + rt) * 64 + sl];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        ob_float4 z = acc[rt][0];
-#pragma unroll
-        for (int b = 1; b < NS; ++b) z += acc[rt][b];
-        z += *reinterpret_cast<const ob_float4 *>(zr + ((size_t)(wr * RT + rt) * 64 + lane) * 4);
-        const int t = rt * 16 + r;
+        for (int w = 1; w < 8; ++w) z += zr[((w * 4 + rn) * RT + rt) * 64 + sl];
+        const int t = rt * 16 + (sl & 15);
         if (t >= T) continue;
-        const int nb = n0 + 4 * gq;
+        const int nb = n0 + rn * 16 + 4 * (sl >> 4);
         if (PARTIAL) {
             if (nb + 3 < N && (N & 3) == 0) {
                 *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = z;

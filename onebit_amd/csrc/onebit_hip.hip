@@ -115,7 +115,7 @@ static void ob_launch_simple(const void *packed, int64_t ldw_bytes, const void *
                        (int)T, (int)K, (int)N);
 }
 
-static inline size_t ob_skinny_lds(int rt) { return (size_t)2 * 16 * rt * (OB_SKINNY_PKT(rt) / rt + 8) * 2; }
+static inline size_t ob_skinny_lds(int rt) { return OB_SKINNY_LDS(rt); }
 
 template <bool PARTIAL, int RT>
 static void ob_launch_skinny(const ObSkinnyArgs &ka, int tiles, hipStream_t s)
