@@ -119,6 +119,7 @@ class LlamaAttentionInf(nn.Module):
         self.k_proj = BitLinearInf(self.hidden_size, Hkv * D, bias=config.attention_bias, dtype=dtype)
         self.v_proj = BitLinearInf(self.hidden_size, Hkv * D, bias=config.attention_bias, dtype=dtype)
         self.o_proj = BitLinearInf(H * D, self.hidden_size, bias=config.attention_bias, dtype=dtype)
+        self.attn_impl = "eager"          # "sdpa": fused kernel for prefill from an empty cache
 
     def forward(self, hidden_states, cos, sin, kv: Tuple[torch.Tensor, torch.Tensor], past_len: int):
         B, S, _ = hidden_states.shape
@@ -139,6 +140,13 @@ class LlamaAttentionInf(nn.Module):
             rep = H // Hkv
             keys = keys.repeat_interleave(rep, dim=1)
             vals = vals.repeat_interleave(rep, dim=1)
+        if self.attn_impl == "sdpa" and S > 1 and past_len == 0:
+            # fused causal attention (the reference offers the same switch: LlamaFlashAttention2 under
+            # config._flash_attn_2_enabled, modeling_bitllama.py:588,862): no [S, S] score tensor in HBM.
+            # Probabilities are not rounded to fp16 on the way, so results differ from the eager path
+            # within fp16 tolerance; parity tests run the eager path.
+            o = nn.functional.scaled_dot_product_attention(q, keys, vals, is_causal=True)
+            return self.o_proj(o.transpose(1, 2).contiguous().reshape(B, S, H * D))
         w = torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(D)       # :546
         if S > 1:
             mask = torch.full((S, L), torch.finfo(w.dtype).min, device=w.device, dtype=w.dtype)
@@ -205,6 +213,14 @@ class OneBitLlamaForCausalLM(nn.Module):
             self._rope = rope_tables(self.config.head_dim, self.config.max_position_embeddings,
                                      self.config.rope_theta, device, dtype)
         return self._rope
+
+    def set_attention(self, impl: str) -> "OneBitLlamaForCausalLM":
+        """"eager" (reference op order, default) or "sdpa" (fused prefill attention)."""
+        if impl not in ("eager", "sdpa"):
+            raise ValueError("attention implementation must be 'eager' or 'sdpa'")
+        for layer in self.model.layers:
+            layer.self_attn.attn_impl = impl
+        return self
 
     def new_cache(self, batch: int = 1, max_len: Optional[int] = None) -> KVCache:
         p = self.lm_head.weight

@@ -80,3 +80,23 @@ def test_convert_train_checkpoint_and_serve(tmp_path):
     assert torch.equal(served(ids), ref)
     out = DecodeEngine(served, max_len=32).generate(ids, max_new_tokens=4)
     assert out.shape == (1, 8)
+
+
+def test_sdpa_prefill_attention_within_fp16_tolerance_of_eager(golden_dir):
+    """The optional fused prefill attention (model.set_attention("sdpa")) against the eager op order
+    and against the reference's recorded prefill logits, same bar as the eager test."""
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, "model_tiny_a.npz"))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    model = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")})
+    model = model.to(dev).eval()
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    eager = model(ids).cpu().numpy()
+    fused = model.set_attention("sdpa")(ids).cpu().numpy()
+    model.set_attention("eager")
+    ref16, ref32 = z["prefill_logits_f16"], z["prefill_logits_f32"]
+    tol = max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
+    assert np.abs(fused - ref16).max() <= tol
+    assert np.abs(fused - eager).max() <= tol
