@@ -112,6 +112,19 @@ int onebit_row_stats(const void *u, float *stats, int64_t T, int64_t n, int dtyp
 int onebit_normalize_rows(const void *u, const float *mean, const float *rstd, const void *bias_or_null,
                           void *y, int64_t T, int64_t n, int dtype, void *stream);
 
+/* ---- row-wise glue around the 1-bit GEMM (prefill and batched decode) ---------------------------
+ * With ONEBIT_FLAG_SKIP_LN the linear kernels leave u = fp16(fp16(z) * g); the LayerNorm that ends
+ * a BitLinearInf then fuses with what the decoder layer does next (modeling_bitllama.py:912-918,
+ * 76-81, 257), one pass over the rows instead of five:
+ * onebit_rows_res_ln_rms: r = hres_in + LayerNorm(u_prev);  hres_out = r;  x = RMSNorm(r) * rms_w
+ * onebit_rows_swiglu:     act = silu(LayerNorm(u_gate)) * LayerNorm(u_up)
+ * All tensors fp16, [T, H] / [T, I] contiguous; H, I % 8 == 0 and <= 16384.
+ */
+int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
+                           void *x, int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
+int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *act, int64_t T, int64_t I, float ln_eps,
+                       void *stream);
+
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's
  * BitLlamaForCausalLMInf (modeling_bitllama.py:1512; decoder layer :856-928, attention

@@ -30,6 +30,8 @@ SYMBOLS = {
     "onebit_scale_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _u, _vp]),
     "onebit_row_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp]),
+    "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_step": (_int, [_vp, _vp, _vp]),      # (onebit_model_t*, onebit_decode_state_t*, stream)
     "onebit_decode_step_batched": (_int, [_vp, _vp, _vp]),   # (onebit_model_t*, onebit_batch_state_t*, stream)

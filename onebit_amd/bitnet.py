@@ -137,7 +137,14 @@ class BitLinearInf(nn.Module):
         return (f"in_features={self.in_features}, out_features={self.out_features}, "
                 f"bias={self.bias is not None}")
 
-    def forward(self, input: torch.Tensor) -> torch.Tensor:
+    def pre_layernorm(self, input: torch.Tensor) -> torch.Tensor:
+        """u = (W . (h * x)) * g, the value the layer's LayerNorm is applied to (bitnet.py:113-116):
+        for callers that fuse that LayerNorm with what follows (onebit_rows_* kernels)."""
+        if self.bias is not None:
+            raise RuntimeError("pre_layernorm: the bias is added after the LayerNorm; use forward")
+        return self.forward(input, _pre_ln=True)
+
+    def forward(self, input: torch.Tensor, _pre_ln: bool = False) -> torch.Tensor:
         K, N = self.in_features, self.out_features
         if input.shape[-1] != K:
             raise RuntimeError(f"BitLinearInf: expected last dim {K}, got {tuple(input.shape)}")
@@ -152,7 +159,7 @@ class BitLinearInf(nn.Module):
                 f"BitLinearInf: input dtype {input.dtype} with parameters of dtype {pdt} "
                 f"(the reference's F.linear raises on this mix as well)")
         code = _dtype_code(cdt)
-        if isinstance(self.layernorm, nn.Identity):
+        if _pre_ln or isinstance(self.layernorm, nn.Identity):
             flags, eps = _lib.FLAG_SKIP_LN, 0.0
         elif isinstance(self.layernorm, nn.LayerNorm) and not self.layernorm.elementwise_affine:
             flags, eps = 0, float(self.layernorm.eps)

@@ -515,6 +515,34 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
     return ob_launch_dec_gemv(a, s);
 }
 
+extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
+                                      void *x, int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
+{
+    if (T < 0 || H <= 0) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: bad size");
+    if (H % 8 != 0 || H > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_res_ln_rms: H = %lld", (long long)H);
+    if (T == 0) return 0;
+    if (!hres_in || !u_prev || !rms_w || !hres_out || !x) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null pointer");
+    if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: dimension too large");
+    ObBNormArgs a = {};
+    a.hres_in = (const _Float16 *)hres_in; a.u_prev = (const _Float16 *)u_prev; a.rms_w = (const _Float16 *)rms_w;
+    a.hres_out = (_Float16 *)hres_out; a.x = (_Float16 *)x; a.H = (int)H; a.rms_eps = rms_eps; a.ln_eps = ln_eps;
+    hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    return ob_launch_status("rows_res_ln_rms");
+}
+
+extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *act, int64_t T, int64_t I, float ln_eps,
+                                  void *stream)
+{
+    if (T < 0 || I <= 0) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: bad size");
+    if (I % 8 != 0 || I > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_swiglu: I = %lld", (long long)I);
+    if (T == 0) return 0;
+    if (!u_gate || !u_up || !act) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: null pointer");
+    if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: dimension too large");
+    ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps};
+    hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    return ob_launch_status("rows_swiglu");
+}
+
 extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
 {
     if (!m || S < 2 || m->n_heads <= 0 || m->max_len <= 0) return 0;

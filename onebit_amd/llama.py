@@ -121,8 +121,10 @@ class LlamaAttentionInf(nn.Module):
         self.o_proj = BitLinearInf(H * D, self.hidden_size, bias=config.attention_bias, dtype=dtype)
         self.attn_impl = "eager"          # "sdpa": fused kernel for prefill from an empty cache
 
-    def forward(self, hidden_states, cos, sin, kv: Tuple[torch.Tensor, torch.Tensor], past_len: int):
+    def forward(self, hidden_states, cos, sin, kv: Tuple[torch.Tensor, torch.Tensor], past_len: int,
+                pre_ln_out: bool = False):
         B, S, _ = hidden_states.shape
+        o_proj = self.o_proj.pre_layernorm if pre_ln_out else self.o_proj
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_dim
         q = self.q_proj(hidden_states).view(B, S, H, D).transpose(1, 2)
         k = self.k_proj(hidden_states).view(B, S, Hkv, D).transpose(1, 2)
@@ -146,7 +148,7 @@ class LlamaAttentionInf(nn.Module):
             # Probabilities are not rounded to fp16 on the way, so results differ from the eager path
             # within fp16 tolerance; parity tests run the eager path.
             o = nn.functional.scaled_dot_product_attention(q, keys, vals, is_causal=True)
-            return self.o_proj(o.transpose(1, 2).contiguous().reshape(B, S, H * D))
+            return o_proj(o.transpose(1, 2).contiguous().reshape(B, S, H * D))
         w = torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(D)       # :546
         if S > 1:
             mask = torch.full((S, L), torch.finfo(w.dtype).min, device=w.device, dtype=w.dtype)
@@ -154,7 +156,7 @@ class LlamaAttentionInf(nn.Module):
             w = w + mask[None, None]
         w = nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)   # :562
         o = torch.matmul(w, vals).transpose(1, 2).contiguous().reshape(B, S, H * D)
-        return self.o_proj(o)
+        return o_proj(o)
 
 
 class LlamaDecoderLayerInf(nn.Module):
@@ -226,6 +228,50 @@ class OneBitLlamaForCausalLM(nn.Module):
         p = self.lm_head.weight
         return KVCache(self.config, batch, max_len or self.config.max_position_embeddings, p.device, p.dtype)
 
+    def set_fused_glue(self, on: bool = True) -> "OneBitLlamaForCausalLM":
+        """Route the row-wise glue between the 1-bit GEMMs through ``onebit_rows_res_ln_rms`` /
+        ``onebit_rows_swiglu`` (o_proj, gate, up and down_proj leave their pre-LayerNorm output; one
+        fused pass does LayerNorm + residual + RMSNorm, another LayerNorm x2 + SiLU * up): fewer passes
+        over the [tokens, hidden] tensors in prefill.  fp16 models, no projection bias.  The fused
+        kernels use the decode engine's one-instruction LayerNorm form, so logits agree with the
+        default path within fp16 tolerance, not bit for bit."""
+        self.fused_glue = bool(on)
+        return self
+
+    def _forward_fused(self, input_ids, cache, past):
+        from . import _lib
+        from .bitnet import _stream_ptr
+        lib = _lib.load()
+        cfg, m = self.config, self.model
+        B, S = input_ids.shape
+        T, H, I = B * S, cfg.hidden_size, cfg.intermediate_size
+        h = m.embed_tokens(input_ids).reshape(T, H)
+        cos, sin = self._rope_tables(h.device, h.dtype)
+        sp = _stream_ptr(h.device)
+
+        def res_ln_rms(hres, u, w):
+            hout, x = torch.empty_like(hres), torch.empty_like(hres)
+            with torch.cuda.device(h.device):
+                _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(), x.data_ptr(),
+                                                      T, H, cfg.rms_norm_eps, 1e-5, sp), "onebit_rows_res_ln_rms")
+            return hout, x
+
+        x = m.layers[0].input_layernorm(h)
+        u_down = None
+        for li, (layer, kv) in enumerate(zip(m.layers, cache.layers)):
+            if u_down is not None:
+                h, x = res_ln_rms(h, u_down, layer.input_layernorm.weight)
+            att = layer.self_attn
+            u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
+            h, x = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight)
+            u_g, u_u = layer.mlp.gate_proj.pre_layernorm(x), layer.mlp.up_proj.pre_layernorm(x)
+            act = torch.empty_like(u_g)
+            with torch.cuda.device(h.device):
+                _lib.check(lib.onebit_rows_swiglu(u_g.data_ptr(), u_u.data_ptr(), act.data_ptr(), T, I, 1e-5, sp), "onebit_rows_swiglu")
+            u_down = layer.mlp.down_proj.pre_layernorm(act)
+        h, x = res_ln_rms(h, u_down, m.norm.weight)
+        return self.lm_head(x.view(B, S, H)).float()
+
     @torch.no_grad()
     def forward(self, input_ids: torch.Tensor, cache: Optional[KVCache] = None) -> torch.Tensor:
         """input_ids [B, S] -> fp32 logits [B, S, vocab]; appends to ``cache`` when given."""
@@ -235,6 +281,10 @@ class OneBitLlamaForCausalLM(nn.Module):
         past = cache.length
         if past + S > cache.max_len:
             raise ValueError("KV cache too small")
+        if getattr(self, "fused_glue", False) and self.lm_head.weight.dtype == torch.float16 and B * S > 1:
+            logits = self._forward_fused(input_ids, cache, past)
+            cache.length = past + S
+            return logits
         h = self.model.embed_tokens(input_ids)
         cos, sin = self._rope_tables(h.device, h.dtype)
         for layer, kv in zip(self.model.layers, cache.layers):

@@ -100,3 +100,26 @@ def test_sdpa_prefill_attention_within_fp16_tolerance_of_eager(golden_dir):
     tol = max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
     assert np.abs(fused - ref16).max() <= tol
     assert np.abs(fused - eager).max() <= tol
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_fused_glue_forward_within_fp16_tolerance(golden_dir, name):
+    """model.set_fused_glue(): pre-LayerNorm outputs + onebit_rows_res_ln_rms / onebit_rows_swiglu, prefill
+    and incremental decode with a cache, against the reference's recorded logits (same bar as the default path)."""
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, f"model_tiny_{name}.npz"))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    model = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")})
+    model = model.to(dev).eval().set_fused_glue(True)
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    ref16, ref32 = z["prefill_logits_f16"], z["prefill_logits_f32"]
+    tol = max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
+    cache = model.new_cache(1, ids.shape[1] + 4)
+    lg = model(ids, cache).cpu().numpy()
+    assert np.abs(lg - ref16).max() <= tol
+    toks = z["greedy_f16"][0]
+    lg2 = model(torch.tensor([[int(toks[0]), int(toks[1])]], device=dev), cache).cpu().numpy()   # 2 tokens on top of the cache
+    assert np.abs(lg2[0, 0] - z["decode_logits_f16"][0][0]).max() <= tol
+    assert np.abs(lg2[0, 1] - z["decode_logits_f16"][0][1]).max() <= tol
