@@ -102,7 +102,8 @@ def measure_roofline(model, dev):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         chain()
-    graph.replay()
+    for _ in range(8):                      # settle clocks / TLBs on the new buffers before timing
+        graph.replay()
     torch.cuda.synchronize(dev)
     reps = max(2, 512 // len(layers))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -269,6 +270,33 @@ def measure_continuous_batch(model, dev, slots=32, steps=40):
             "note": "steady-state decode, all slots active, greedy; per GPU"}
 
 
+def measure_prefill_model(model, dev, B=8, S=2048):
+    """BASELINE configs[2]: whole-model prefill of B x S tokens (1-bit GEMMs + fused row glue +
+    the vendor's fused attention), tokens/s and the 1-bit layers' share expressed in TFLOP/s."""
+    cfg = model.config
+    S = min(S, cfg.max_position_embeddings)
+    ids = torch.randint(0, cfg.vocab_size, (B, S), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev)
+    model.set_attention("sdpa").set_fused_glue(True)
+    try:
+        with torch.no_grad():
+            model(ids[:1, :128]); model(ids)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n = 2
+            for _ in range(n):
+                model(ids)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / n
+    finally:
+        model.set_attention("eager").set_fused_glue(False)
+        torch.cuda.empty_cache()
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    w1 = L * (4 * H * H + 3 * H * I)
+    return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "tokens_per_s": round(B * S / dt, 1),
+            "onebit_layer_TFLOPs_equivalent": round(2.0 * B * S * w1 / dt / 1e12, 1),
+            "attention": "sdpa", "glue": "onebit_rows_res_ln_rms + onebit_rows_swiglu", "per": "GPU"}
+
+
 def measure_cpu_baseline(cfg):
     """The oracle's reference-style CPU path (dense +-1 matrix rebuilt on every call, then a dense
     fp32 GEMV, *g, LayerNorm -- bitnet.py:98-118 restated in C), single thread, on the 7 projections
@@ -369,6 +397,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    roof = None
+    if rank == 0 and not args.no_roofline:      # right after the decode phase: same thermal / clock state as the headline
+        roof = measure_roofline(model, dev)
     prefill = None
     if not args.no_prefill:
         try:
@@ -387,10 +418,14 @@ def main():
             serve = measure_continuous_batch(model, dev)
         except Exception as e:
             serve = {"error": "%s: %s" % (type(e).__name__, e)}
-    roof = cpu = None
+    pmodel = None
+    if not args.no_prefill and rank == 0:
+        try:
+            pmodel = measure_prefill_model(model, dev)
+        except Exception as e:
+            pmodel = {"error": "%s: %s" % (type(e).__name__, e)}
+    cpu = None
     if rank == 0:
-        if not args.no_roofline:
-            roof = measure_roofline(model, dev)
         if not args.no_cpu_baseline and world == 1:
             cpu = measure_cpu_baseline(cfg)
     if world > 1:
@@ -419,6 +454,8 @@ def main():
             out["decode_k_sharded"] = ksd
         if serve is not None:
             out["continuous_batch"] = serve
+        if pmodel is not None:
+            out["prefill_model"] = pmodel
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
