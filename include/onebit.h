@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 2
+#define ONEBIT_ABI_VERSION 3
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -177,9 +177,16 @@ typedef struct onebit_decode_state {
      * per head reads the whole history (the fast form up to a few hundred tokens).                 */
     int32_t attn_splits;        /* S, 2..16                                                    */
     void *attn_scratch;         /* onebit_attn_scratch_bytes(model, S) bytes, zero-filled once */
+    /* Per-tile LayerNorm partials: every GEMV launch publishes, per 16 output rows, (sum, sum of
+     * squared deviations from the tile mean) of its pre-LayerNorm u; the consuming launch combines
+     * them (parallel-variance formula) instead of re-reading and re-reducing the vector in each of
+     * its workgroups.  fp32 [onebit_decode_stats_floats(model)], caller-owned, never read before
+     * it is written (no initialisation needed).                                                  */
+    float *tile_stats;
 } onebit_decode_state_t;
 
 size_t onebit_attn_scratch_bytes(const onebit_model_t *model, int32_t splits);
+size_t onebit_decode_stats_floats(const onebit_model_t *model);
 
 int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t *state, void *stream);
 
@@ -226,6 +233,13 @@ typedef struct onebit_fused_in {
     const int32_t *token;
     void *hres_out;
     float rms_eps, ln_eps;
+    /* optional per-tile LayerNorm partials (see onebit_decode_state_t.tile_stats), each
+     * fp32 [ceil(n / 4096) * 512]: tile t of a vector holds (sum, M2) at [2t], [2t+1].
+     * st_prev / st_gate / st_up: partials of u_prev / u_gate / u_up written by the launch that
+     * produced them (all that the prologue reads must be given, or none: the statistics are then
+     * recomputed from the vectors).  st_out[i]: where projection i publishes its own, or NULL.   */
+    const float *st_prev, *st_gate, *st_up;
+    float *st_out[3];
 } onebit_fused_in_t;
 int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
                       const onebit_fused_in_t *in, void *stream);

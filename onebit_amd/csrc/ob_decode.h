@@ -34,6 +34,7 @@ struct ObProj {
     const _Float16 *h;           // input_factor [K]
     const _Float16 *g;           // weight_scale [N]
     _Float16 *u;                 // out: pre-LayerNorm u [N]
+    float *st;                   // out (optional): per 16-row tile (sum, M2) of u, interleaved [ceil(N/16)][2]
     int N, K, ldw;
 };
 
@@ -53,6 +54,10 @@ struct ObGemvArgs {
     _Float16 *hres_out;            // EMBED_RMS / RES_LN_RMS: residual stream out [K] (workgroup 0 writes)
     const _Float16 *rms_w;         // RMSNorm weight [K]
     const _Float16 *u_gate, *u_up; // SWIGLU: pre-LN gate / up [K]
+    // per-tile (sum, M2) pairs written by the producers of u_prev / u_gate / u_up (PST kernels): the
+    // LayerNorm statistics are then a wave-local combine of K/16 pairs -- no pass over the vector, no
+    // workgroup barrier.  Buffers hold a multiple of 256 tiles (reads beyond K/16 are masked).
+    const float *st_prev, *st_gate, *st_up;
     float rms_eps, ln_eps;
     int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
     unsigned long long *dbg;       // profiling builds only: per-workgroup phase timestamps [grid][8]
@@ -128,6 +133,118 @@ __device__ __forceinline__ _Float16 ob_ln_apply_h(_Float16 u, float rstd, float 
 __device__ __forceinline__ float ob_silu_h(float x)   // fp16 silu: fp32 math, one rounding
 {
     return ob_round_h(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)));
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Producer-side LayerNorm partials.  The thread rows that finalise a 16-row tile hold its u values
+// in one 16-lane DPP row: they publish (sum, M2 = sum of squared deviations from the tile mean).
+// A consumer combines the n/16 pairs with the parallel-variance formula (Chan et al.):
+//   mean = sum_i s_i / n,   M2 = sum_i [ M2_i + c_i (s_i / c_i - mean)^2 ],   var = M2 / n (biased)
+// -- per wave, redundantly, 4 tiles per lane and 256-tile block: two DPP wave reductions instead of a
+// pass over the vector, a shifted one-pass sum and a workgroup barrier.
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+struct ObTileStats { ob_float4 a[NV][2]; };
+
+template <int NV>
+__device__ __forceinline__ void ob_tiles_load(ObTileStats<NV> &r, const float *st, int lane)
+{
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8);
+        r.a[v][0] = p[0];
+        r.a[v][1] = p[1];
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void ob_tiles_combine(const ObTileStats<NV> &r, int n, float eps, int lane, float &mean, float &rstd)
+{
+    float cnt[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = (v * 64 + lane) * 4 + i;
+            cnt[v][i] = (float)min(max(n - 16 * t, 0), 16);
+            const float si = r.a[v][i >> 1][2 * (i & 1)];
+            s += cnt[v][i] > 0.f ? si : 0.f;
+        }
+    }
+    s = ob_wave_sum(s);
+    const float inv_n = __builtin_amdgcn_rcpf((float)n);
+    mean = s * inv_n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float si = r.a[v][i >> 1][2 * (i & 1)], qi = r.a[v][i >> 1][2 * (i & 1) + 1];
+            const float d = si * __builtin_amdgcn_rcpf(fmaxf(cnt[v][i], 1.f)) - mean;
+            m2 += cnt[v][i] > 0.f ? __builtin_fmaf(cnt[v][i] * d, d, qi) : 0.f;
+        }
+    }
+    m2 = ob_wave_sum(m2);
+    rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
+}
+
+// The same for a vector whose length is a runtime value (<= 16384): blocks of 256 tiles beyond
+// n / 16 are neither loaded nor counted.
+struct ObTileStatsRt { ObTileStats<4> t; };
+__device__ __forceinline__ void ob_tiles_load_rt(ObTileStatsRt &r, const float *st, int n, int lane)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        r.t.a[v][0] = r.t.a[v][1] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+        if (v * 4096 < n) {
+            const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8);
+            r.t.a[v][0] = p[0];
+            r.t.a[v][1] = p[1];
+        }
+    }
+}
+__device__ __forceinline__ void ob_tiles_combine_rt(const ObTileStatsRt &r, int n, float eps, int lane, float &mean, float &rstd)
+{
+    ob_tiles_combine<4>(r.t, n, eps, lane, mean, rstd);     // counts of the blocks not loaded are zero
+}
+
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ float ob_row16_sum(float v)
+{
+    v += OB_DPP_F(v, 0xB1, 0xF);
+    v += OB_DPP_F(v, 0x4E, 0xF);
+    v += OB_DPP_F(v, 0x141, 0xF);
+    v += OB_DPP_F(v, 0x140, 0xF);
+    return v;
+}
+
+// 4x4 dword transpose inside each quad of lanes: lane l, dword d  <-  lane d, dword l.  With the
+// contiguous element ownership (lane 4Q + i holds elements 32Q + 8i .. + 7 as 4 fp16 pairs) this
+// yields the strided ownership of the integer path (lane (Q, jp): elements 32Q + 8i + 2jp + s), so
+// the prologue vectors are fetched with ONE 16-byte load per lane instead of four 4-byte ones
+// (the texture addresser, not the data, bounded the load phase: 4x the instructions for the same
+// cache lines).  Two butterfly stages (lane ^ 2 then lane ^ 1), 16 VALU ops.
+__device__ __forceinline__ ob_half8 ob_quad_transpose(const ob_half8 x, int lane)
+{
+    ob_u32x4 d = __builtin_bit_cast(ob_u32x4, x);
+    const bool hi = lane & 2, odd = lane & 1;
+    {
+        const uint32_t s0 = hi ? d[0] : d[2], s1 = hi ? d[1] : d[3];
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x4E, 0xF, 0xF, false);
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
+        d[0] = hi ? r0 : d[0]; d[1] = hi ? r1 : d[1];
+        d[2] = hi ? d[2] : r0; d[3] = hi ? d[3] : r1;
+    }
+    {
+        const uint32_t s0 = odd ? d[0] : d[1], s2 = odd ? d[2] : d[3];
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);
+        const uint32_t r2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s2, 0xB1, 0xF, 0xF, false);
+        d[0] = odd ? r0 : d[0]; d[1] = odd ? d[1] : r0;
+        d[2] = odd ? r2 : d[2]; d[3] = odd ? d[3] : r2;
+    }
+    return __builtin_bit_cast(ob_half8, d);
 }
 
 // 16 MFMAs for one 512-weight chunk of a 16-row tile.  w4: this lane's 4 packed words (row = lane&15,
@@ -244,11 +361,13 @@ __device__ __forceinline__ void ob_st8(_Float16 *p, const ob_half8 v)
 // dynamic LDS: activations (fp16: 2 B/k, i8: 4 digit bytes/k) per projection | cross-wave partials |
 //              reduction slots (256 floats)
 // ---------------------------------------------------------------------------------------------
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
     constexpr int MT = MS * NPROJ;
-    constexpr bool SD = MATH == 1;          // strided element ownership (see ob_ld8)
+    // PST: LayerNorm statistics of the prologue inputs come from the producers' per-tile partials
+    constexpr bool SD = false;              // prologue vectors are always fetched contiguously (one 16-byte
+                                            // load per lane); the integer path transposes inside quads later
     // the projection descriptors live in SGPRs; selection by slot is compile-time
     const ObProj PP[3] = {A.p[0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,10 +411,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
-        const int base = SD ? (v * OB_DEC_WAVES + wave) * 512 + (lane >> 2) * 32 + (lane & 3) * 2
-                            : (v * OB_DEC_THREADS + tid) * 8;
+        const int base = (v * OB_DEC_THREADS + tid) * 8;     // = chunk (v * 8 + wave), elements 8 * lane .. + 7
         valid[v] = base < K;                    // K % 32 == 0: a thread's 8 elements are all in or all out
-        vbase[v] = valid[v] ? base : (SD ? (lane & 3) * 2 : 0);
+        vbase[v] = valid[v] ? base : 0;
         if (PRO == OB_P_PLAIN) {
             v0[v] = ob_ld8<SD>(A.xin + vbase[v]);
         } else if (PRO == OB_P_SWIGLU) {
@@ -311,8 +429,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) hp[p][v] = ob_ld8<SD>(PP[p].h + vbase[v]);
     }
-    if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
-    if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
+    ObTileStats<KV> ts0, ts1;
+    if (PST) {
+        if (PRO == OB_P_SWIGLU) { ob_tiles_load<KV>(ts0, A.st_gate, lane); ob_tiles_load<KV>(ts1, A.st_up, lane); }
+        if (PRO == OB_P_RES_LN_RMS) ob_tiles_load<KV>(ts0, A.st_prev, lane);
+    } else {
+        if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
+        if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
+    }
     // 1b. embedding row: the one dependent load (token id first), once per token
     if (PRO == OB_P_EMBED_RMS) {
         const _Float16 *row = A.embed + (int64_t)(*A.token) * K;
@@ -325,7 +449,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     int n_out = 0;
     _Float16 g_h = (_Float16)0;
     _Float16 *u_out = nullptr;
-    int p_out = 0;
+    float *st_out = nullptr;
+    int p_out = 0, tile_out = 0, tile_cnt = 0;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         if (j == jo) {
@@ -335,6 +460,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             n_out = min(n_raw, PP[p].N - 1);
             g_h = PP[p].g[n_out];
             u_out = PP[p].u;
+            st_out = tval[j] ? PP[p].st : nullptr;
+            tile_out = trow[j] >> 4;
+            tile_cnt = min(PP[p].N - trow[j], 16);
             p_out = p;
         }
     }
@@ -370,19 +498,26 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         load_items(NA, NITEM);
         __builtin_amdgcn_sched_barrier(0);
     } else if (PRO == OB_P_SWIGLU) {
-        const float c0 = (float)c0h, c1 = (float)c1h;
-        ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
-#pragma unroll
-        for (int v = 0; v < KV; ++v) {
-            if (valid[v]) { ob_stats8(v0[v], c0, sg2, qg2); ob_stats8(v1[v], c1, su2, qu2); }
-        }
-        float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
-        ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
-        load_items(NA, NITEM);
-        __builtin_amdgcn_sched_barrier(0);
         float mg, rg, mu, ru;
-        ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
-        ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
+        if (PST) {
+            load_items(NA, NITEM);
+            __builtin_amdgcn_sched_barrier(0);
+            ob_tiles_combine<KV>(ts0, K, A.ln_eps, lane, mg, rg);
+            ob_tiles_combine<KV>(ts1, K, A.ln_eps, lane, mu, ru);
+        } else {
+            const float c0 = (float)c0h, c1 = (float)c1h;
+            ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                if (valid[v]) { ob_stats8(v0[v], c0, sg2, qg2); ob_stats8(v1[v], c1, su2, qu2); }
+            }
+            float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
+            ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
+            load_items(NA, NITEM);
+            __builtin_amdgcn_sched_barrier(0);
+            ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
+            ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
+        }
         const float ng = -mg * rg, nu = -mu * ru;
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
@@ -400,18 +535,24 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     } else {
         ob_half8 hv[KV];
         if (PRO == OB_P_RES_LN_RMS) {
-            const float c0 = (float)c0h;
-            ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
-#pragma unroll
-            for (int v = 0; v < KV; ++v) {
-                if (valid[v]) ob_stats8(v0[v], c0, s2, q2);
-            }
-            float s[2] = {s2[0] + s2[1], q2[0] + q2[1]};
-            ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
-            load_items(NA, NITEM);
-            __builtin_amdgcn_sched_barrier(0);
             float mean, rstd;
-            ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
+            if (PST) {
+                load_items(NA, NITEM);
+                __builtin_amdgcn_sched_barrier(0);
+                ob_tiles_combine<KV>(ts0, K, A.ln_eps, lane, mean, rstd);
+            } else {
+                const float c0 = (float)c0h;
+                ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < KV; ++v) {
+                    if (valid[v]) ob_stats8(v0[v], c0, s2, q2);
+                }
+                float s[2] = {s2[0] + s2[1], q2[0] + q2[1]};
+                ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
+                load_items(NA, NITEM);
+                __builtin_amdgcn_sched_barrier(0);
+                ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
+            }
             const float nmr = -mean * rstd;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
@@ -499,13 +640,24 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         __syncthreads();
+        float uval = 0.f;
         if (fin) {
             const int r = tid & 15;
             float z = 0.f;
 #pragma unroll
             for (int w = 0; w < OB_DEC_WAVES; ++w) z += lds_red[((jo * OB_DEC_WAVES + w) << 4) + r];
             // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
-            u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);
+            const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);
+            u_out[n_out] = uh;
+            uval = (float)uh;
+        }
+        // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
+        if (tid < MT * 16) {
+            const float cnt = (float)tile_cnt;
+            const float sm = ob_row16_sum(fin ? uval : 0.f);
+            const float dv = fin ? uval - sm * __builtin_amdgcn_rcpf(cnt) : 0.f;
+            const float m2 = ob_row16_sum(dv * dv);
+            if (st_out && (tid & 15) == 0) *reinterpret_cast<ob_float2 *>(st_out + 2 * tile_out) = (ob_float2){sm, m2};
         }
         OB_STAMP(7);
     } else {
@@ -526,7 +678,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             ob_u16x2 mx = {0, 0};
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
-                ah[p][v] = xh[v] * hp[p][v];
+                ah[p][v] = ob_quad_transpose(xh[v] * hp[p][v], lane);    // -> strided ownership (see ob_ld8)
                 const ob_u32x4 bits = __builtin_bit_cast(ob_u32x4, ah[p][v]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d)             // |a| as fp16 bit patterns order like unsigned integers
@@ -652,6 +804,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         __syncthreads();
+        float uval = 0.f;
         if (fin) {
             const int r = tid & 15;
             float z = 0.f;
@@ -660,7 +813,17 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 const ob_float4 t = *reinterpret_cast<const ob_float4 *>(lds_red + (((jo * OB_DEC_WAVES + w) * 16 + r) << 2));
                 z += (t[0] + t[1]) + (t[2] + t[3]);
             }
-            u_out[n_out] = (_Float16)(ob_round_h(z) * (float)g_h);    // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
+            const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);   // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
+            u_out[n_out] = uh;
+            uval = (float)uh;
+        }
+        // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
+        if (tid < MT * 16) {
+            const float cnt = (float)tile_cnt;
+            const float sm = ob_row16_sum(fin ? uval : 0.f);
+            const float dv = fin ? uval - sm * __builtin_amdgcn_rcpf(cnt) : 0.f;
+            const float m2 = ob_row16_sum(dv * dv);
+            if (st_out && (tid & 15) == 0) *reinterpret_cast<ob_float2 *>(st_out + 2 * tile_out) = (ob_float2){sm, m2};
         }
         OB_STAMP(7);
     }
@@ -676,6 +839,7 @@ struct ObAttnArgs {
     _Float16 *kcache, *vcache;           // [Hkv, max_len, D]
     _Float16 *out;                       // [H*D]
     const int *pos;                      // device [slots]: position of the new token (= tokens already cached); < 0 = idle slot
+    const float *st_q, *st_k, *st_v;     // PST kernels: per-tile (sum, M2) partials of u_q / u_k / u_v from the q|k|v GEMV
     int H, Hkv, D, max_len;
     float ln_eps;
     long long slot_stride;               // elements between the caches of consecutive slots (blockIdx.y); rows of
@@ -712,6 +876,7 @@ __device__ __forceinline__ float ob_rows_max(float v)
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+template <bool PST>
 __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 {
     ObAttnArgs A = A_in;
@@ -751,9 +916,12 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
         vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
     }
     const int pos = *A.pos;
-    if (pos < 0) return;                          // idle slot (uniform for the workgroup, before any barrier)
+    if (pos < 0 || pos >= A.max_len) return;      // idle slot, or a step past the cache (host error: never write or
+                                                  // read beyond the allocation); uniform, before any barrier
     const int L = pos + 1;
-    const _Float16 cqh = A.u_q[0], ckh = A.u_k[0], cvh = A.u_v[0];
+    ObTileStatsRt tq, tk, tv;
+    if (PST) { ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane); }
+    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
     const int half = D >> 1;
     const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
@@ -761,26 +929,33 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
     __builtin_amdgcn_sched_barrier(0);
 
-    // LayerNorm statistics of the three rows (each workgroup recomputes them)
-    const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
-    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
-    for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
-    }
-    float s[6];
+    // LayerNorm statistics of the three rows: from the producer's tile partials (every wave, no
+    // barrier), or recomputed from the rows by each workgroup
+    float mq, rq, mk, rk, mv, rv;
+    if (PST) {
+        ob_tiles_combine_rt(tq, NQ, A.ln_eps, lane, mq, rq);
+        ob_tiles_combine_rt(tk, NK, A.ln_eps, lane, mk, rk);
+        ob_tiles_combine_rt(tv, NK, A.ln_eps, lane, mv, rv);
+    } else {
+        const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
+        ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
+        for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
+        }
+        float s[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
-    ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);                        // barrier 1
+        for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
+        ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);                        // barrier 1
+        ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
+        ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
+        ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
+    }
     if (tid < 128) {
         float qe = 0.f, ke = 0.f, ve = 0.f;
         if (tid < D) {
-            float mq, rq, mk, rk, mv, rv;
-            ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
-            ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
-            ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
             // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16
             const float c = (float)cosh_, sn = (float)sinh_;
             const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
@@ -941,6 +1116,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(con
     _Float16 *k_s = q_s + 128;
     float *sl = reinterpret_cast<float *>(k_s + 128);        // [chunk] this split's scores (second pass)
     const int pos = *A.pos;
+    if (pos < 0 || pos >= A.max_len) return;                 // a step past the cache: touch nothing
     const int L = pos + 1;
     const int p_lo = split * B.chunk, p_hi = min(L, p_lo + B.chunk);
     if (p_lo >= L) return;                                   // empty split (uniform)
@@ -954,25 +1130,33 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(con
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
     const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
     const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
-    const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
-    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
-    for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
-        ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
-    }
-    float s[6];
+    float mq, rq, mk, rk, mv, rv;
+    if (A.st_q) {                                            // producer's tile partials (uniform branch)
+        ObTileStatsRt tq, tk, tv;
+        ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane);
+        ob_tiles_combine_rt(tq, NQ, A.ln_eps, lane, mq, rq);
+        ob_tiles_combine_rt(tk, NK, A.ln_eps, lane, mk, rk);
+        ob_tiles_combine_rt(tv, NK, A.ln_eps, lane, mv, rv);
+    } else {
+        const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
+        ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
+        for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
+            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
+        }
+        float s[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
-    ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);
+        for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
+        ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);
+        ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
+        ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
+        ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
+    }
     if (tid < 128) {
         float qe = 0.f, ke = 0.f;
         if (tid < D) {
-            float mq, rq, mk, rk, mv, rv;
-            ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
-            ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
-            ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
             const float c = (float)cosh_, sn = (float)sinh_;
             const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
             const float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
@@ -1055,6 +1239,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_pv_kernel(const O
     float *po = reinterpret_cast<float *>(smem);             // [8 waves][128]
     int *flag = reinterpret_cast<int *>(po + OB_ATTN_WAVES * 128);
     const int pos = *A.pos;                                  // the position has NOT been advanced yet
+    if (pos < 0 || pos >= A.max_len) return;
     const int L = pos + 1;
     const int p_lo = split * B.chunk, p_hi = min(L, p_lo + B.chunk);
     if (p_lo >= L) return;
@@ -1136,6 +1321,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_pv_kernel(const O
 // ---------------------------------------------------------------------------------------------
 struct ObHeadArgs {
     const _Float16 *hres_in, *u_prev, *rms_w;   // residual stream, last down_proj pre-LN, final norm weight
+    const float *st_prev;                       // optional: tile partials of u_prev from the down_proj GEMV
     const _Float16 *lm_w;                       // [V, K]
     _Float16 *logits;                           // [V] fp16 (the reference's logits before .float())
     float *part_val; int *part_idx;             // [grid] per-workgroup argmax
@@ -1169,9 +1355,15 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
                 }
             }
         }
-        ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
         float mean, rstd;
-        ob_ln_stats(s[0], s[1], c, K, A.ln_eps, mean, rstd);
+        if (A.st_prev) {
+            ObTileStatsRt tp;
+            ob_tiles_load_rt(tp, A.st_prev, K, lane);
+            ob_tiles_combine_rt(tp, K, A.ln_eps, lane, mean, rstd);
+        } else {
+            ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
+            ob_ln_stats(s[0], s[1], c, K, A.ln_eps, mean, rstd);
+        }
         float ss[1] = {0.f};
 #pragma unroll
         for (int v = 0; v < OB_DEC_MAXV; ++v) {
@@ -1257,7 +1449,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
 }
 
 __global__ __launch_bounds__(256) void ob_dec_argmax_kernel(const float *part_val, const int *part_idx, int nparts,
-                                                            int *token, int *pos, int *out_tokens, int max_out)
+                                                            int *token, int *pos, int *out_tokens, int max_out, int vocab)
 {
     __shared__ float sv[256];
     __shared__ int si[256];
@@ -1277,8 +1469,11 @@ __global__ __launch_bounds__(256) void ob_dec_argmax_kernel(const float *part_va
     }
     if (threadIdx.x == 0) {
         const int p = *pos;
-        *token = si[0];
-        if (out_tokens && p < max_out) out_tokens[p] = si[0];
+        // all-NaN logits leave the index at its initial value: clamp, or the next replay would read
+        // embed[token] out of bounds (no host in the loop under graph replay)
+        const int tk = (si[0] >= 0 && si[0] < vocab) ? si[0] : 0;
+        *token = tk;
+        if (out_tokens && p < max_out) out_tokens[p] = tk;
         *pos = p + 1;
     }
 }

@@ -35,6 +35,25 @@ static int ob_launch_status(const char *what)
 
 static inline bool ob_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
+// Function attributes and device properties are per DEVICE, not per process: one process may
+// drive several GPUs (hipSetDevice between calls), so "already done" is keyed by the current device.
+#define OB_MAX_DEVICES 64
+static inline int ob_device_index()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OB_MAX_DEVICES) dev = 0;
+    return dev;
+}
+template <typename F>
+static inline void ob_set_max_lds_once(F kernel, bool (&done)[OB_MAX_DEVICES], int bytes)
+{
+    const int dev = ob_device_index();
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done[dev] = true;
+    }
+}
+
 extern "C" int onebit_abi_version(void) { return ONEBIT_ABI_VERSION; }
 extern "C" const char *onebit_last_error(void) { return g_err; }
 
@@ -121,11 +140,8 @@ template <bool PARTIAL, int RT>
 static void ob_launch_skinny(const ObSkinnyArgs &ka, int tiles, hipStream_t s)
 {
     const size_t lds = ob_skinny_lds(RT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)ob_skinny_f16_kernel<PARTIAL, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_skinny_f16_kernel<PARTIAL, RT>, attr_set, (int)lds);
     hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT>), dim3((unsigned)tiles), dim3(512), lds, s, ka);
 }
 
@@ -361,19 +377,19 @@ extern "C" int onebit_normalize_rows(const void *u, const float *mean, const flo
 
 static int ob_cu_count()
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+    static int cus[OB_MAX_DEVICES] = {};
+    const int dev = ob_device_index();
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
-    return cus;
+    return cus[dev];
 }
 
-static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *name)
+static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *name, float *st = nullptr)
 {
+    d.st = st;
     if (!s.weight || !s.input_factor || !s.weight_scale || !u)
         return ob_fail(ONEBIT_E_ARG, "decode_step: null pointer in projection %s", name);
     if (s.K % 32 != 0 || s.ldw_bytes % 4 != 0 || s.ldw_bytes < s.K / 8 || s.N <= 0)
@@ -387,16 +403,26 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST>
+static void ob_launch_dec_gemv_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST>, attr_set, 160 * 1024);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+}
+
+// PST (statistics from the producers' tile partials) exists for the prologues that normalise an
+// input vector; chosen when the caller supplied the partials of every such vector
 template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ>
 static void ob_launch_dec_gemv_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    if constexpr (PRO == OB_P_RES_LN_RMS) {
+        if (a.st_prev) return ob_launch_dec_gemv_t2<KV, MS, ALIGNED, PRO, MATH, NPROJ, true>(a, G, lds, s);
     }
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    if constexpr (PRO == OB_P_SWIGLU) {
+        if (a.st_gate && a.st_up) return ob_launch_dec_gemv_t2<KV, MS, ALIGNED, PRO, MATH, NPROJ, true>(a, G, lds, s);
+    }
+    ob_launch_dec_gemv_t2<KV, MS, ALIGNED, PRO, MATH, NPROJ, false>(a, G, lds, s);
 }
 
 // the (prologue, projection count) pairs a decoder layer needs; other pairs are not instantiated
@@ -543,6 +569,29 @@ extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *ac
     return ob_launch_status("rows_swiglu");
 }
 
+// Tile partials: one slot per pre-LayerNorm vector of a layer (q, k, v, o, gate, up, down), each
+// 2 floats per 16-row tile, padded to whole blocks of 256 tiles (the consumers read whole blocks).
+struct ObStatsLayout { size_t off[7]; size_t total; };
+static ObStatsLayout ob_stats_layout(const onebit_model_t *m)
+{
+    const int64_t n[7] = {(int64_t)m->n_heads * m->head_dim, (int64_t)m->n_kv_heads * m->head_dim,
+                          (int64_t)m->n_kv_heads * m->head_dim, m->hidden, m->intermediate, m->intermediate, m->hidden};
+    ObStatsLayout sl;
+    size_t o = 0;
+    for (int i = 0; i < 7; ++i) {
+        sl.off[i] = o;
+        o += (size_t)((n[i] + 4095) / 4096) * 512;
+    }
+    sl.total = o;
+    return sl;
+}
+
+extern "C" size_t onebit_decode_stats_floats(const onebit_model_t *m)
+{
+    if (!m || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 || m->hidden <= 0 || m->intermediate <= 0) return 0;
+    return ob_stats_layout(m).total;
+}
+
 extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
 {
     if (!m || S < 2 || m->n_heads <= 0 || m->max_len <= 0) return 0;
@@ -644,7 +693,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         at.ln_eps = m->ln_eps; at.slot_stride = (long long)m->n_kv_heads * m->max_len * D;
         const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
-        hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads, B), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+        hipLaunchKernelGGL(ob_dec_attn_kernel<false>, dim3(m->n_heads, B), dim3(OB_ATTN_THREADS), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
         if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
@@ -699,8 +748,11 @@ extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, 
     int rc;
     for (int p = 0; p < nproj; ++p) {
         if (projs[p].K != projs[0].K) return ob_fail(ONEBIT_E_SHAPE, "fused_gemv: projections must share in_features");
-        if ((rc = ob_fill_proj(a.p[p], projs[p], outs[p], "fused"))) return rc;
+        if ((rc = ob_fill_proj(a.p[p], projs[p], outs[p], "fused", in->st_out[p]))) return rc;
     }
+    a.st_prev = in->st_prev; a.st_gate = in->st_gate; a.st_up = in->st_up;
+    for (const float *sp : {a.st_prev, a.st_gate, a.st_up, (const float *)in->st_out[0], (const float *)in->st_out[1], (const float *)in->st_out[2]})
+        if (sp && !ob_aligned(sp, 16)) return ob_fail(ONEBIT_E_ALIGN, "fused_gemv: tile statistics must be 16-byte aligned");
     a.xin = (const _Float16 *)in->xin; a.embed = (const _Float16 *)in->embed; a.token = in->token;
     a.hres_in = (const _Float16 *)in->hres_in; a.u_prev = (const _Float16 *)in->u_prev;
     a.hres_out = (_Float16 *)in->hres_out; a.rms_w = (const _Float16 *)in->rms_w;
@@ -729,9 +781,16 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         !st->u_o || !st->u_gate || !st->u_up || !st->u_down || !st->logits || !st->part_val || !st->part_idx ||
         !m->embed || !m->final_norm_w || !m->lm_head || !m->rope_cos || !m->rope_sin)
         return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer");
+    if (!st->tile_stats || !ob_aligned(st->tile_stats, 16))
+        return ob_fail(ONEBIT_E_ARG, "decode_step: tile_stats (onebit_decode_stats_floats floats, 16-byte aligned) is required");
     hipStream_t s = (hipStream_t)stream;
     const int H = m->hidden, I = m->intermediate, D = m->head_dim;
     _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
+    // tile partials of the seven pre-LayerNorm vectors of a layer (reused by every layer)
+    ObStatsLayout sl = ob_stats_layout(m);
+    float *ts = st->tile_stats;
+    float *ts_q = ts + sl.off[0], *ts_k = ts + sl.off[1], *ts_v = ts + sl.off[2], *ts_o = ts + sl.off[3],
+          *ts_gate = ts + sl.off[4], *ts_up = ts + sl.off[5], *ts_down = ts + sl.off[6];
     int rc;
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
@@ -740,9 +799,9 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         // K1: residual (+LN of previous down) -> RMSNorm -> q, k, v
         ObGemvArgs a = {};
         a.nproj = 3; a.K = H;
-        if ((rc = ob_fill_proj(a.p[0], L.q, st->u_q, "q_proj"))) return rc;
-        if ((rc = ob_fill_proj(a.p[1], L.k, st->u_k, "k_proj"))) return rc;
-        if ((rc = ob_fill_proj(a.p[2], L.v, st->u_v, "v_proj"))) return rc;
+        if ((rc = ob_fill_proj(a.p[0], L.q, st->u_q, "q_proj", ts_q))) return rc;
+        if ((rc = ob_fill_proj(a.p[1], L.k, st->u_k, "k_proj", ts_k))) return rc;
+        if ((rc = ob_fill_proj(a.p[2], L.v, st->u_v, "v_proj", ts_v))) return rc;
         if (L.q.K != H || L.k.K != H || L.v.K != H || L.q.N != (int64_t)m->n_heads * D || L.k.N != (int64_t)m->n_kv_heads * D ||
             L.v.N != L.k.N || L.o.K != L.q.N || L.o.N != H || L.gate.K != H || L.up.K != H || L.gate.N != I ||
             L.up.N != I || L.down.K != I || L.down.N != H)
@@ -750,6 +809,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         a.prologue = l == 0 ? OB_P_EMBED_RMS : OB_P_RES_LN_RMS;
         a.embed = (const _Float16 *)m->embed; a.token = st->token;
         a.hres_in = hA; a.u_prev = (const _Float16 *)st->u_down; a.hres_out = hB;
+        a.st_prev = ts_down;
         a.rms_w = (const _Float16 *)L.input_layernorm_w;
         a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(a, s))) return rc;
@@ -760,6 +820,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
+        at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
         if (st->attn_splits > 1 && st->attn_scratch) {
             const int S = st->attn_splits;
             if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);
@@ -779,35 +840,39 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         } else {
             const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
             if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
-            hipLaunchKernelGGL(ob_dec_attn_kernel, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+            if (at.st_q) hipLaunchKernelGGL(ob_dec_attn_kernel<true>, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+            else hipLaunchKernelGGL(ob_dec_attn_kernel<false>, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
             if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
         }
         // K3: o_proj
         ObGemvArgs o = {};
         o.nproj = 1; o.K = (int)L.o.K; o.prologue = OB_P_PLAIN; o.xin = (const _Float16 *)st->attn_out;
-        if ((rc = ob_fill_proj(o.p[0], L.o, st->u_o, "o_proj"))) return rc;
+        if ((rc = ob_fill_proj(o.p[0], L.o, st->u_o, "o_proj", ts_o))) return rc;
         o.rms_eps = m->rms_eps; o.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(o, s))) return rc;
         // K4: residual + LN(u_o) -> RMSNorm -> gate, up
         ObGemvArgs gu = {};
         gu.nproj = 2; gu.K = H; gu.prologue = OB_P_RES_LN_RMS;
-        if ((rc = ob_fill_proj(gu.p[0], L.gate, st->u_gate, "gate_proj"))) return rc;
-        if ((rc = ob_fill_proj(gu.p[1], L.up, st->u_up, "up_proj"))) return rc;
+        if ((rc = ob_fill_proj(gu.p[0], L.gate, st->u_gate, "gate_proj", ts_gate))) return rc;
+        if ((rc = ob_fill_proj(gu.p[1], L.up, st->u_up, "up_proj", ts_up))) return rc;
         gu.hres_in = hB; gu.u_prev = (const _Float16 *)st->u_o; gu.hres_out = hA;
+        gu.st_prev = ts_o;
         gu.rms_w = (const _Float16 *)L.post_attention_layernorm_w;
         gu.rms_eps = m->rms_eps; gu.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(gu, s))) return rc;
         // K5: silu(LN(gate)) * LN(up) -> down
         ObGemvArgs dn = {};
         dn.nproj = 1; dn.K = I; dn.prologue = OB_P_SWIGLU;
-        if ((rc = ob_fill_proj(dn.p[0], L.down, st->u_down, "down_proj"))) return rc;
+        if ((rc = ob_fill_proj(dn.p[0], L.down, st->u_down, "down_proj", ts_down))) return rc;
         dn.u_gate = (const _Float16 *)st->u_gate; dn.u_up = (const _Float16 *)st->u_up;
+        dn.st_gate = ts_gate; dn.st_up = ts_up;
         dn.rms_eps = m->rms_eps; dn.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(dn, s))) return rc;
     }
     // final norm + lm_head + argmax
     ObHeadArgs hd = {};
     hd.hres_in = hA; hd.u_prev = (const _Float16 *)st->u_down; hd.rms_w = (const _Float16 *)m->final_norm_w;
+    hd.st_prev = ts_down;
     hd.lm_w = (const _Float16 *)m->lm_head; hd.logits = (_Float16 *)st->logits;
     hd.part_val = st->part_val; hd.part_idx = st->part_idx; hd.hres_out = hB;
     hd.K = H; hd.V = m->vocab; hd.rms_eps = m->rms_eps; hd.ln_eps = m->ln_eps;
@@ -817,6 +882,6 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     hipLaunchKernelGGL(ob_dec_lmhead_kernel, dim3(G), dim3(OB_DEC_THREADS), head_lds, s, hd);
     if ((rc = ob_launch_status("decode_step(lm_head)"))) return rc;
     hipLaunchKernelGGL(ob_dec_argmax_kernel, dim3(1), dim3(256), 0, s, (const float *)st->part_val,
-                       (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out);
+                       (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out, m->vocab);
     return ob_launch_status("decode_step(argmax)");
 }

@@ -46,7 +46,8 @@ class _State(ctypes.Structure):
     _fields_ = [("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
-                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp)]
+                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp),
+                ("tile_stats", _vp)]
 
 
 class _BatchState(ctypes.Structure):
@@ -58,23 +59,34 @@ class _BatchState(ctypes.Structure):
 class _FusedIn(ctypes.Structure):
     _fields_ = [("xin", _vp), ("embed", _vp), ("hres_in", _vp), ("u_prev", _vp), ("rms_w", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("token", _vp), ("hres_out", _vp),
-                ("rms_eps", _f), ("ln_eps", _f)]
+                ("rms_eps", _f), ("ln_eps", _f), ("st_prev", _vp), ("st_gate", _vp), ("st_up", _vp),
+                ("st_out", _vp * 3)]
 
 
 PRO_PLAIN, PRO_EMBED_RMS, PRO_RES_LN_RMS, PRO_SWIGLU = 0, 1, 2, 3
 
 
-def fused_gemv(mods, outs, prologue, rms_eps=1e-6, ln_eps=1e-5, **inputs):
+def tile_stats_floats(n: int) -> int:
+    """fp32 elements of the per-tile LayerNorm partials of an n-vector (whole blocks of 256 tiles)."""
+    return ((n + 4095) // 4096) * 512
+
+
+def fused_gemv(mods, outs, prologue, rms_eps=1e-6, ln_eps=1e-5, stats_out=None, **inputs):
     """One ``onebit_fused_gemv`` launch on the current stream: projections ``mods`` (BitLinearInf
     sharing in_features) write their pre-LayerNorm outputs to ``outs`` (fp16 [N_i] tensors);
-    ``inputs`` are the prologue tensors named as in ``onebit_fused_in_t``."""
+    ``inputs`` are the prologue tensors named as in ``onebit_fused_in_t`` (``st_prev`` / ``st_gate``
+    / ``st_up``: tile partials of the corresponding vectors, fp32 ``tile_stats_floats(n)``);
+    ``stats_out[i]``: where projection i publishes its own partials (or None)."""
     lib = _lib.load()
     n = len(mods)
     projs = (_Proj * n)(*[_proj(m) for m in mods])
     optr = (_vp * n)(*[o.data_ptr() for o in outs])
     ptr = lambda k: inputs[k].data_ptr() if inputs.get(k) is not None else None
+    so = list(stats_out or []) + [None] * 3
+    st_out = (_vp * 3)(*[t.data_ptr() if t is not None else None for t in so[:3]])
     fin = _FusedIn(ptr("xin"), ptr("embed"), ptr("hres_in"), ptr("u_prev"), ptr("rms_w"), ptr("u_gate"),
-                   ptr("u_up"), ptr("token"), ptr("hres_out"), rms_eps, ln_eps)
+                   ptr("u_up"), ptr("token"), ptr("hres_out"), rms_eps, ln_eps, ptr("st_prev"), ptr("st_gate"),
+                   ptr("st_up"), st_out)
     dev = outs[0].device
     with torch.cuda.device(dev):
         rc = lib.onebit_fused_gemv(ctypes.cast(projs, _vp), ctypes.cast(optr, _vp), n, prologue,
@@ -157,20 +169,33 @@ class DecodeEngine:
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
-                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None)
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None)
+        self.lib.onebit_decode_stats_floats.restype = ctypes.c_size_t
+        self.lib.onebit_decode_stats_floats.argtypes = [ctypes.POINTER(_Model)]
+        self._tile_stats = torch.zeros(max(int(self.lib.onebit_decode_stats_floats(ctypes.byref(self._model))), 1),
+                                       dtype=torch.float32, device=dev)
+        self._state.tile_stats = self._tile_stats.data_ptr()
         self.lib.onebit_decode_step.restype = ctypes.c_int
         self.lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), _vp]
         self.graph = self.graph_long = None
         self._prompt_len = 0
         self._steps = 0                     # host-side count of tokens in the cache (chooses the graph)
         self._long_from = int(long_context_from) if long_context_from and self.max_len > long_context_from else 0
-        self._launch()                      # warm-up: validates arguments, sets function attributes
-        torch.cuda.synchronize(dev)
-        if use_graph:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch()
-            self.graph = g
+        # the one-workgroup-per-head attention keeps the scores of every position in LDS (64 KiB limit
+        # in onebit_decode_step): beyond that only the split-KV form exists, and it serves every position
+        self._short_ok = 512 + 3 * 128 * 2 + 8 * 128 * 4 + 4 * self.max_len <= 64 * 1024
+        if not self._short_ok:
+            if not long_context_from:
+                raise ValueError(f"max_len {self.max_len} needs the split-KV attention (long_context_from > 0)")
+            self._long_from = 1
+        if self._short_ok:
+            self._launch()                  # warm-up: validates arguments, sets function attributes
+            torch.cuda.synchronize(dev)
+            if use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch()
+                self.graph = g
         if self._long_from:
             S = max(2, min(int(attn_splits), 16, self.max_len // 128))
             self.lib.onebit_attn_scratch_bytes.restype = ctypes.c_size_t
@@ -216,14 +241,22 @@ class DecodeEngine:
         return logits
 
     def set_state(self, token: int, pos: int):
+        """Arm the engine with ``token`` at cache position ``pos`` (the KV cache must hold ``pos`` tokens)."""
+        if not 0 <= int(pos) < self.max_len:
+            raise ValueError(f"set_state: position {pos} outside the KV cache [0, {self.max_len})")
+        if not 0 <= int(token) < self.cfg.vocab_size:
+            raise ValueError(f"set_state: token {token} outside the vocabulary")
         self.token.fill_(int(token))
         self.pos.fill_(int(pos))
         self._steps = int(pos)
 
     def step(self):
         """Decode one token (asynchronous): consumes the device-side token, appends to the KV cache,
-        leaves the next greedy token on the device."""
-        long = bool(self._long_from) and self._steps >= self._long_from
+        leaves the next greedy token on the device.  Raises when the KV cache is full: the kernels
+        index the cache, the rope tables and their score buffers by the device-side position."""
+        if self._steps >= self.max_len:
+            raise RuntimeError(f"DecodeEngine.step: KV cache full ({self.max_len} positions); build the engine with a larger max_len")
+        long = bool(self._long_from) and (self._steps >= self._long_from or not self._short_ok)
         g = self.graph_long if long else self.graph
         if g is not None:
             g.replay()
@@ -236,15 +269,28 @@ class DecodeEngine:
         return self.buf["logits"].float()
 
     @torch.no_grad()
-    def generate(self, input_ids: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int, eos_token_id=None) -> torch.Tensor:
+        """Greedy decoding as the reference's ``greedy_search`` (generation/utils.py:2491-2540) for one
+        sequence: the prompt followed by up to ``max_new_tokens`` tokens; with ``eos_token_id`` (int or
+        list) the output ends with the first EOS token, as the reference's stopping criterion does
+        (the steps are enqueued without a host round trip, the cut is made afterwards)."""
+        S = input_ids.shape[1]
+        if S + max_new_tokens > self.max_len:
+            raise ValueError(f"generate: prompt {S} + max_new_tokens {max_new_tokens} exceeds the engine's max_len {self.max_len}")
         self.prefill(input_ids)
-        n = min(max_new_tokens - 1, self.max_len - self._prompt_len - 1)
+        n = max_new_tokens - 1
         for _ in range(max(n, 0)):
             self.step()
         torch.cuda.synchronize(self.dev)
-        new: List[int] = [self.first_token]
+        new: List[int] = [self.first_token] if max_new_tokens > 0 else []
         if n > 0:
             new += self.out_tokens[self._prompt_len:self._prompt_len + n].tolist()
+        if eos_token_id is not None:
+            eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
+            for i, t in enumerate(new):
+                if t in eos:
+                    new = new[:i + 1]
+                    break
         return torch.cat([input_ids.to(self.dev), torch.tensor([new], device=self.dev, dtype=input_ids.dtype)], dim=1)
 
 
@@ -263,6 +309,8 @@ class BatchedDecodeStep:
             raise ValueError("BatchedDecodeStep needs an fp16 model")
         if not 2 <= batch <= 64:
             raise ValueError("batch must be in 2..64")
+        if max_len > cfg.max_position_embeddings:
+            raise ValueError("max_len exceeds max_position_embeddings (the rope tables have that many rows)")
         self.model, self.cfg, self.dev, self.batch = model, cfg, p.device, batch
         self.lib = _lib.load()
         dev, f16 = self.dev, torch.float16

@@ -294,19 +294,36 @@ class OneBitLlamaForCausalLM(nn.Module):
         return self.lm_head(h).float()
 
     @torch.no_grad()
-    def generate(self, input_ids: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
-        """Greedy search (generation/utils.py:2338, loop :2491-2540): argmax of the last position."""
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int, eos_token_id=None, pad_token_id=None) -> torch.Tensor:
+        """Greedy search (generation/utils.py:2338, loop :2491-2540): argmax of the last position.
+        With ``eos_token_id`` (int or list) a row that produced EOS is finished: its later tokens are
+        ``pad_token_id`` (required then for B > 1, as in the reference, :2543-2546) and generation stops
+        when every row is finished (:2562-2570).  Rows of ``input_ids`` must have equal length: there is
+        no attention_mask / left padding on this path (the reference's padded batches are not reproduced)."""
         B, S = input_ids.shape
         cache = self.new_cache(B, S + max_new_tokens)
+        eos = None
+        if eos_token_id is not None:
+            eos = torch.tensor(list(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else [int(eos_token_id)],
+                               device=input_ids.device)
+            if pad_token_id is None:
+                if B > 1:
+                    raise ValueError("generate: eos_token_id with batch > 1 needs pad_token_id (generation/utils.py:2543)")
+                pad_token_id = int(eos[0])
+        unfinished = torch.ones(B, 1, dtype=torch.long, device=input_ids.device)
         logits = self.forward(input_ids, cache)
         out = [input_ids]
-        nxt = logits[:, -1].argmax(-1, keepdim=True)
-        for _ in range(max_new_tokens):
-            out.append(nxt)
-            if len(out) - 1 == max_new_tokens:
-                break
-            logits = self.forward(nxt, cache)
+        for i in range(max_new_tokens):
             nxt = logits[:, -1].argmax(-1, keepdim=True)
+            if eos is not None:
+                nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+            out.append(nxt)
+            if eos is not None:
+                unfinished = unfinished * (nxt != eos.view(1, -1)).all(dim=1, keepdim=True).long()
+                if int(unfinished.max()) == 0:
+                    break
+            if i + 1 < max_new_tokens:
+                logits = self.forward(nxt, cache)
         return torch.cat(out, dim=1)
 
 

@@ -119,6 +119,9 @@ class ContinuousBatcher:
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
         self.model, self.cfg, self.dev, self.dtype = model, model.config, p.device, p.dtype
+        if max_len > model.config.max_position_embeddings:
+            raise ValueError(f"max_len {max_len} exceeds max_position_embeddings {model.config.max_position_embeddings} "
+                             "(the rope tables have that many rows)")
         self.sched = Scheduler(max_batch, max_len, max_step_tokens)
         cfg = self.cfg
         shape = (max_batch, cfg.num_key_value_heads, max_len, cfg.head_dim)

@@ -1,0 +1,215 @@
+"""Full-size GPU parity (BASELINE.json configs 2-5 at their real layer widths), straight against the
+oracle where the oracle finishes in seconds, through size-independent properties elsewhere.
+
+  * the fused decode GEMV launches (what `bench.py` times) at 7B and 13B shapes against the oracle's
+    pre-LayerNorm u -- directly, not via the module path -- including the chain o -> gate|up -> down
+    through the producers' per-tile LayerNorm partials (the product path of onebit_decode_step);
+  * config 3: ONE launch of the prefill GEMM at T = 8 x 2048 = 16384 tokens, 4096 -> 11008, 64 sampled
+    token rows against the oracle (reference semantics: bitnet.py:112-122);
+  * config 2: the 32-layer 7B engine against the module path for 4 teacher-forced tokens;
+  * config 5: the native batched step with 32 slots on 13B-shaped layers against single-sequence
+    generate.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP16_ULP = 2.0 ** -10
+
+
+def _mk(K, N, seed, dev):
+    from onebit_amd import BitLinearInf
+    rng = np.random.default_rng(seed)
+    packed = rng.integers(0, 256, (N, K // 8), dtype=np.uint8).view(np.int8)
+    flip = lambda n: np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    h = (0.1 * (0.5 + rng.random(K)) * flip(K)).astype(np.float16)
+    g = (0.1 * (0.5 + rng.random(N)) * flip(N)).astype(np.float16)
+    m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
+    m.weight.data = torch.from_numpy(packed).to(dev)
+    m.input_factor.data = torch.from_numpy(h).to(dev)
+    m.weight_scale.data = torch.from_numpy(g).to(dev)
+    return m, packed, h, g
+
+
+def _check_u(got, ref, tag, frac=0.02):
+    """pre-LayerNorm u: within 2 fp16 ulps everywhere, different at all on < frac of the elements."""
+    got, ref = got.astype(np.float32), ref.astype(np.float32)
+    ulp = np.maximum(np.abs(ref), 2.0 ** -14) * FP16_ULP
+    assert (np.abs(got - ref) <= 2.001 * ulp).all(), (tag, float((np.abs(got - ref) / ulp).max()))
+    assert (got != ref).mean() <= frac, (tag, float((got != ref).mean()))
+
+
+def _tile_stats_ref(u):
+    """(sum, M2) per 16-element tile of an fp16 vector, fp64 reference."""
+    u = u.astype(np.float64).reshape(-1, 16)
+    s = u.sum(1)
+    m2 = ((u - s[:, None] / 16.0) ** 2).sum(1)
+    return s, m2
+
+
+@pytest.mark.parametrize("H,I", [(4096, 11008), (5120, 13824)])
+def test_fused_gemv_chain_vs_oracle(coracle, H, I):
+    from onebit_amd.engine import PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU, fused_gemv, tile_stats_floats
+    dev = torch.device("cuda:0")
+    f16 = torch.float16
+    rng = np.random.default_rng(11)
+    o_m, o_w, o_h, o_g = _mk(H, H, 1, dev)
+    g_m, g_w, g_h, g_g = _mk(H, I, 2, dev)
+    u_m, u_w, u_h, u_g = _mk(H, I, 3, dev)
+    d_m, d_w, d_h, d_g = _mk(I, H, 4, dev)
+    x = rng.standard_normal(H).astype(np.float16)
+    hres = rng.standard_normal(H).astype(np.float16)
+    rms_w = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = lambda n: torch.full((tile_stats_floats(n),), float("nan"), dtype=torch.float32, device=dev)   # poisoned: never read unwritten
+
+    # 1. PLAIN (o_proj), publishing its tile partials
+    u_o = torch.empty(H, dtype=f16, device=dev)
+    st_o = st(H)
+    fused_gemv([o_m], [u_o], PRO_PLAIN, xin=t(x), stats_out=[st_o])
+    _, u_o_ref = coracle.forward_f16(o_w, x[None], o_h, o_g, None, return_pre_ln=True)
+    _check_u(u_o.cpu().numpy(), u_o_ref[0], "o")
+    s_ref, m2_ref = _tile_stats_ref(u_o.cpu().numpy())
+    got = st_o.cpu().numpy()[: 2 * (H // 16)].reshape(-1, 2)
+    np.testing.assert_allclose(got[:, 0], s_ref, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(got[:, 1], m2_ref, rtol=1e-4, atol=1e-4)
+
+    # 2. RES_LN_RMS (gate | up): statistics of u_o from the partials, against the oracle fed with the
+    #    host-side fp16 statement of the prologue (modeling_bitllama.py:912-918, 76-81)
+    uo32 = u_o.float().cpu().numpy().astype(np.float32)
+    mean, var = uo32.mean(dtype=np.float64), uo32.var(dtype=np.float64)
+    ln = ((uo32 - mean) / np.sqrt(var + 1e-5)).astype(np.float16)
+    r = (hres + ln).astype(np.float16)
+    r32 = r.astype(np.float32)
+    rs = 1.0 / np.sqrt((r32.astype(np.float64) ** 2).mean() + 1e-6)
+    xn = (rms_w * (r32 * rs).astype(np.float16)).astype(np.float16)
+    u_gate, u_up = torch.empty(I, dtype=f16, device=dev), torch.empty(I, dtype=f16, device=dev)
+    hout = torch.empty(H, dtype=f16, device=dev)
+    st_g, st_u = st(I), st(I)
+    for use_stats in (True, False):
+        kw = dict(st_prev=st_o) if use_stats else {}
+        fused_gemv([g_m, u_m], [u_gate, u_up], PRO_RES_LN_RMS, hres_in=t(hres), u_prev=u_o, hres_out=hout, rms_w=t(rms_w),
+                   stats_out=[st_g, st_u], **kw)
+        hd = hout.cpu().numpy()
+        assert (hd != r).mean() <= 0.01 and np.abs(hd.astype(np.float32) - r32).max() <= 2 * FP16_ULP * max(1.0, np.abs(r32).max())
+        # feed the oracle with the residual stream the kernel actually formed (isolates the GEMV)
+        hk = hd.astype(np.float32)
+        rs_k = 1.0 / np.sqrt((hk.astype(np.float64) ** 2).mean() + 1e-6)
+        xn_k = (rms_w * (hk * rs_k).astype(np.float16)).astype(np.float16)
+        _, ug_ref = coracle.forward_f16(g_w, xn_k[None], g_h, g_g, None, return_pre_ln=True)
+        _, uu_ref = coracle.forward_f16(u_w, xn_k[None], u_h, u_g, None, return_pre_ln=True)
+        _check_u(u_gate.cpu().numpy(), ug_ref[0], "gate stats=%s" % use_stats, frac=0.03)
+        _check_u(u_up.cpu().numpy(), uu_ref[0], "up stats=%s" % use_stats, frac=0.03)
+    assert float(np.abs(xn.astype(np.float32) - xn_k.astype(np.float32)).max()) <= 4 * FP16_ULP * max(1.0, np.abs(xn).max())
+
+    # 3. SWIGLU (down) from the gate / up partials vs the oracle on the host-side activation
+    u_down = torch.empty(H, dtype=f16, device=dev)
+    outs = {}
+    for use_stats in (True, False):
+        kw = dict(st_gate=st_g, st_up=st_u) if use_stats else {}
+        fused_gemv([d_m], [u_down], PRO_SWIGLU, u_gate=u_gate, u_up=u_up, **kw)
+        outs[use_stats] = u_down.cpu().numpy().copy()
+    def lnv(v):
+        v = v.astype(np.float32)
+        return ((v - v.mean(dtype=np.float64)) / np.sqrt(v.var(dtype=np.float64) + 1e-5)).astype(np.float16)
+    gl, ul = lnv(u_gate.cpu().numpy()), lnv(u_up.cpu().numpy())
+    gl32 = gl.astype(np.float32)
+    act = ((gl32 / (1.0 + np.exp(-gl32))).astype(np.float16) * ul).astype(np.float16)
+    _, ud_ref = coracle.forward_f16(d_w, act[None], d_h, d_g, None, return_pre_ln=True)
+    for use_stats, got in outs.items():
+        # the activation itself may differ by an fp16 ulp in a few elements (exp / rcp approximations)
+        rel = np.linalg.norm(got.astype(np.float32) - ud_ref[0].astype(np.float32)) / np.linalg.norm(ud_ref[0].astype(np.float32))
+        assert rel <= 1e-3, (use_stats, rel)
+        ulp = np.maximum(np.abs(ud_ref[0].astype(np.float32)), 2.0 ** -14) * FP16_ULP
+        assert (np.abs(got.astype(np.float32) - ud_ref[0].astype(np.float32)) > 2.001 * ulp).mean() <= 0.05, use_stats
+    # both statistics paths are the same arithmetic up to the fp32 rounding of mean / rstd
+    assert (outs[True] != outs[False]).mean() <= 0.02
+
+
+def test_prefill_full_size_vs_oracle(coracle):
+    """BASELINE config 3: [8, 2048, 4096] -> 11008 in ONE call (T = 16384, the launch bench.py times);
+    64 token rows spread over the workgroup grid are checked against the oracle (u within 2 ulp,
+    y rel-L2 <= 1e-3), the rest through the LayerNorm property (zero mean, unit variance)."""
+    dev = torch.device("cuda:0")
+    K, N, T = 4096, 11008, 8 * 2048
+    m, packed, h, g = _mk(K, N, 21, dev)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(T, K, generator=gen).half()
+    xd = x.to(dev)
+    y = m(xd.view(8, 2048, K)).view(T, N)
+    m.layernorm = torch.nn.Identity()
+    u = m(xd)
+    rows = sorted(set(np.random.default_rng(3).integers(0, T, 60).tolist()) | {0, 127, 128, T - 1})
+    xs = x[rows].numpy()
+    y_ref, u_ref = coracle.forward_f16(packed, xs, h, g, None, return_pre_ln=True)
+    un, yn = u[rows].cpu().numpy(), y[rows].cpu().numpy()
+    for i, r in enumerate(rows):
+        _check_u(un[i], u_ref[i], "row %d" % r)
+        rel = np.linalg.norm(yn[i].astype(np.float32) - y_ref[i].astype(np.float32)) / np.linalg.norm(y_ref[i].astype(np.float32))
+        assert rel <= 1e-3, (r, rel)
+    yf = y.float()
+    assert float(yf.mean(dim=1).abs().max()) <= 2e-3
+    assert float((yf.var(dim=1, unbiased=False) - 1.0).abs().max()) <= 5e-3
+
+
+def test_engine_7b_32_layers_vs_module_path():
+    """BASELINE config 2 at full depth: the 32-layer 7B engine (graph replay) against the module path
+    for 4 teacher-forced tokens."""
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig.llama_7b()
+    model = build_synthetic_model(cfg, seed=77, device=dev)
+    ids = torch.randint(0, cfg.vocab_size, (1, 12), generator=torch.Generator().manual_seed(1)).to(dev)
+    cache = model.new_cache(1, 32)
+    lg = model(ids, cache)
+    tok = lg[:, -1].argmax(-1, keepdim=True)
+    ref_logits, ref_toks = [], [int(tok)]
+    for _ in range(4):
+        lg = model(tok, cache)
+        ref_logits.append(lg[0, -1].cpu().numpy())
+        tok = lg[:, -1].argmax(-1, keepdim=True)
+        ref_toks.append(int(tok))
+    eng = DecodeEngine(model, max_len=32)
+    eng.prefill(ids)
+    assert eng.first_token == ref_toks[0]
+    ref = np.stack(ref_logits)
+    for i in range(4):
+        eng.set_state(ref_toks[i], ids.shape[1] + i)
+        eng.step()
+        got = eng.logits().cpu().numpy()
+        err = np.abs(got - ref[i]).max()
+        assert err <= 6e-3 * np.abs(ref).max(), (i, err)
+        assert np.isfinite(got).all()
+    del eng, model, cache
+    torch.cuda.empty_cache()
+
+
+def test_native_batched_step_32_slots_13b_layers():
+    """BASELINE config 5 shape: 32 slots, 13B layer widths (hidden 5120 / intermediate 13824 / 40 heads),
+    2 layers, mixed prompt lengths and budgets: per-request tokens equal single-sequence generate
+    (fp16 near-ties tolerated at the first divergence)."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.serving import ContinuousBatcher
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=1024, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                            num_attention_heads=40, max_position_embeddings=96)
+    model = build_synthetic_model(cfg, seed=13, device=dev)
+    g = torch.Generator().manual_seed(4)
+    lens = [(int(n), int(m)) for n, m in zip(torch.randint(1, 40, (36,), generator=g), torch.randint(2, 10, (36,), generator=g))]
+    reqs = [(torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist(), m) for n, m in lens]
+    cb = ContinuousBatcher(model, max_batch=32, max_len=64)
+    assert cb._native is not None
+    rids = [cb.add_request(p, m) for p, m in reqs]
+    out = cb.run()
+    assert cb.graph_steps > 0
+    for rid, (p, m) in zip(rids, reqs):
+        ref = model.generate(torch.tensor([p], device=dev), m)[0, len(p):].tolist()
+        got = out[rid]
+        assert len(got) == m
+        if got != ref:
+            j = next(i for i in range(m) if got[i] != ref[i])
+            lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
+            assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)

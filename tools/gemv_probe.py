@@ -11,7 +11,8 @@ if os.environ.get("OB_PROFILE_BUILD"):     # profiling build (-DOB_PROFILE_ABLAT
                            os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
     _lib.LIB_PATH = so
 from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
-from onebit_amd.engine import fused_gemv, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU
+from onebit_amd.engine import fused_gemv, tile_stats_floats, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU
+USE_STATS = os.environ.get("OB_PROBE_STATS", "1") == "1"      # producers' tile partials (the decode_step path)
 
 dev = torch.device("cuda:0")
 cfg = OneBitLlamaConfig(num_hidden_layers=int(os.environ.get("OB_PROBE_LAYERS", "8")))
@@ -22,19 +23,22 @@ hres, uprev, hout = (torch.randn(H, device=dev).to(f16) for _ in range(3))
 ug, uu = torch.randn(I, device=dev).to(f16), torch.randn(I, device=dev).to(f16)
 oq, ok, ov, oo, og, ou, od = (torch.empty(n, device=dev, dtype=f16) for n in (H, H, H, H, I, I, H))
 L = list(model.model.layers)
+stH, stI, stI2 = (torch.zeros(tile_stats_floats(n), device=dev) for n in (H, I, I))
+so = lambda *a: list(a) if USE_STATS else None
+si = lambda **kw: kw if USE_STATS else {}
 
 def chain(kind):
     for l in L:
         if kind == "o":
-            fused_gemv([l.self_attn.o_proj], [oo], PRO_PLAIN, xin=hres)
+            fused_gemv([l.self_attn.o_proj], [oo], PRO_PLAIN, xin=hres, stats_out=so(stH))
         elif kind == "qkv":
             fused_gemv([l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj], [oq, ok, ov], PRO_RES_LN_RMS,
-                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.input_layernorm.weight)
+                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.input_layernorm.weight, stats_out=so(stH, stH, stH), **si(st_prev=stH))
         elif kind == "gateup":
             fused_gemv([l.mlp.gate_proj, l.mlp.up_proj], [og, ou], PRO_RES_LN_RMS,
-                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.post_attention_layernorm.weight)
+                       hres_in=hres, u_prev=uprev, hres_out=hout, rms_w=l.post_attention_layernorm.weight, stats_out=so(stI, stI2), **si(st_prev=stH))
         else:
-            fused_gemv([l.mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu)
+            fused_gemv([l.mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu, stats_out=so(stH), **si(st_gate=stI, st_up=stI2))
 
 out = []
 for kind in ("o", "qkv", "gateup", "down"):
@@ -49,4 +53,4 @@ for kind in ("o", "qkv", "gateup", "down"):
         g.replay()
     e1.record(); torch.cuda.synchronize()
     out.append("%s %.2f" % (kind, e0.elapsed_time(e1) * 1e3 / (20 * len(L))))
-print("OB_ABLATE=%s us/launch:" % os.environ.get("OB_ABLATE", "0"), "  ".join(out))
+print("OB_ABLATE=%s stats=%d us/launch:" % (os.environ.get("OB_ABLATE", "0"), USE_STATS), "  ".join(out))
