@@ -161,17 +161,14 @@ __device__ __forceinline__ void ob_tiles_load(ObTileStats<NV> &r, const float *s
 template <int NV>
 __device__ __forceinline__ void ob_tiles_combine(const ObTileStats<NV> &r, int n, float eps, int lane, float &mean, float &rstd)
 {
-    float cnt[NV][4];
+    // n % 16 == 0 (host-checked): every tile below n / 16 is full, the rest of a block is masked
+    const int ntiles = n >> 4;
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = (v * 64 + lane) * 4 + i;
-            cnt[v][i] = (float)min(max(n - 16 * t, 0), 16);
-            const float si = r.a[v][i >> 1][2 * (i & 1)];
-            s += cnt[v][i] > 0.f ? si : 0.f;
-        }
+        for (int i = 0; i < 4; ++i)
+            s += (v * 64 + lane) * 4 + i < ntiles ? r.a[v][i >> 1][2 * (i & 1)] : 0.f;
     }
     s = ob_wave_sum(s);
     const float inv_n = __builtin_amdgcn_rcpf((float)n);
@@ -181,9 +178,9 @@ __device__ __forceinline__ void ob_tiles_combine(const ObTileStats<NV> &r, int n
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float si = r.a[v][i >> 1][2 * (i & 1)], qi = r.a[v][i >> 1][2 * (i & 1) + 1];
-            const float d = si * __builtin_amdgcn_rcpf(fmaxf(cnt[v][i], 1.f)) - mean;
-            m2 += cnt[v][i] > 0.f ? __builtin_fmaf(cnt[v][i] * d, d, qi) : 0.f;
+            const float d = __builtin_fmaf(r.a[v][i >> 1][2 * (i & 1)], 0.0625f, -mean);
+            const float t = __builtin_fmaf(16.0f * d, d, r.a[v][i >> 1][2 * (i & 1) + 1]);
+            m2 += (v * 64 + lane) * 4 + i < ntiles ? t : 0.f;
         }
     }
     m2 = ob_wave_sum(m2);
@@ -192,22 +189,40 @@ __device__ __forceinline__ void ob_tiles_combine(const ObTileStats<NV> &r, int n
 
 // The same for a vector whose length is a runtime value (<= 16384): blocks of 256 tiles beyond
 // n / 16 are neither loaded nor counted.
-struct ObTileStatsRt { ObTileStats<4> t; };
+struct ObTileStatsRt { ob_float4 a[2]; };          // block 0 (the first 4096 elements); further blocks are re-read in the combine
 __device__ __forceinline__ void ob_tiles_load_rt(ObTileStatsRt &r, const float *st, int n, int lane)
 {
+    const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)lane * 8);
+    r.a[0] = p[0];
+    r.a[1] = p[1];
+}
+__device__ __forceinline__ void ob_tiles_combine_rt(const ObTileStatsRt &r, const float *st, int n, float eps, int lane, float &mean, float &rstd)
+{
+    const int ntiles = n >> 4;
+    float s = 0.f;
+    for (int v = 0; v * 256 < ntiles; ++v) {               // uniform trip count; 1 for vectors up to 4096
+        ob_float4 a0 = r.a[0], a1 = r.a[1];
+        if (v) { const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8); a0 = p[0]; a1 = p[1]; }
+        const int t = (v * 64 + lane) * 4;
+        s += (t < ntiles ? a0[0] : 0.f) + (t + 1 < ntiles ? a0[2] : 0.f) + (t + 2 < ntiles ? a1[0] : 0.f) + (t + 3 < ntiles ? a1[2] : 0.f);
+    }
+    s = ob_wave_sum(s);
+    const float inv_n = __builtin_amdgcn_rcpf((float)n);
+    mean = s * inv_n;
+    float m2 = 0.f;
+    for (int v = 0; v * 256 < ntiles; ++v) {
+        ob_float4 a0 = r.a[0], a1 = r.a[1];
+        if (v) { const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8); a0 = p[0]; a1 = p[1]; }
+        const int t = (v * 64 + lane) * 4;
+        const float sv[4] = {a0[0], a0[2], a1[0], a1[2]}, qv[4] = {a0[1], a0[3], a1[1], a1[3]};
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        r.t.a[v][0] = r.t.a[v][1] = (ob_float4){0.f, 0.f, 0.f, 0.f};
-        if (v * 4096 < n) {
-            const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8);
-            r.t.a[v][0] = p[0];
-            r.t.a[v][1] = p[1];
+        for (int i = 0; i < 4; ++i) {
+            const float d = __builtin_fmaf(sv[i], 0.0625f, -mean);
+            m2 += t + i < ntiles ? __builtin_fmaf(16.0f * d, d, qv[i]) : 0.f;
         }
     }
-}
-__device__ __forceinline__ void ob_tiles_combine_rt(const ObTileStatsRt &r, int n, float eps, int lane, float &mean, float &rstd)
-{
-    ob_tiles_combine<4>(r.t, n, eps, lane, mean, rstd);     // counts of the blocks not loaded are zero
+    m2 = ob_wave_sum(m2);
+    rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
 }
 
 // sum over the 16 lanes of a DPP row, in every lane of the row
@@ -366,16 +381,25 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 {
     constexpr int MT = MS * NPROJ;
     // PST: LayerNorm statistics of the prologue inputs come from the producers' per-tile partials
+#ifdef OB_STRIDED_LOADS                     // A/B switch (tools/phase_probe.py): 4-byte strided prologue loads, no transpose
+    constexpr bool SD = MATH == 1;
+#else
     constexpr bool SD = false;              // prologue vectors are always fetched contiguously (one 16-byte
                                             // load per lane); the integer path transposes inside quads later
+#endif
     // the projection descriptors live in SGPRs; selection by slot is compile-time
     const ObProj PP[3] = {A.p[0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;              // launch floor
-#define OB_STAMP(i) do { if (A.dbg && (threadIdx.x & 63) == 0) A.dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    // phase timestamps stay in registers and are written once at the end (a store per stamp would sit
+    // in the same vmcnt queue as the loads being measured)
+    unsigned long long stamp_[16] = {};
+#define OB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define OB_STAMP_FLUSH() do { if (A.dbg && (threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) A.dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + i_] = stamp_[i_]; } } while (0)
 #else
 #define OB_STAMP(i) do { } while (0)
+#define OB_STAMP_FLUSH() do { } while (0)
 #endif
     OB_STAMP(0);
     const int K = A.K;
@@ -411,9 +435,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
-        const int base = (v * OB_DEC_THREADS + tid) * 8;     // = chunk (v * 8 + wave), elements 8 * lane .. + 7
+        const int base = SD ? (v * OB_DEC_WAVES + wave) * 512 + (lane >> 2) * 32 + (lane & 3) * 2
+                            : (v * OB_DEC_THREADS + tid) * 8;     // = chunk (v * 8 + wave), elements 8 * lane .. + 7
         valid[v] = base < K;                    // K % 32 == 0: a thread's 8 elements are all in or all out
-        vbase[v] = valid[v] ? base : 0;
+        vbase[v] = valid[v] ? base : (SD ? (lane & 3) * 2 : 0);
         if (PRO == OB_P_PLAIN) {
             v0[v] = ob_ld8<SD>(A.xin + vbase[v]);
         } else if (PRO == OB_P_SWIGLU) {
@@ -443,41 +468,68 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
         for (int v = 0; v < KV; ++v) v1[v] = ob_ld8<SD>(row + vbase[v]);
     }
-    // 1c. epilogue scale g of the output row this thread will finalise: thread (slot j, row r)
+    // 1c. epilogue scale g of the output row this thread will finalise: thread (slot j, row r).
+    //     Branch-free: the slot's tile / projection are SELECTED and the load is unconditional.  (A
+    //     load inside "if (j == jo)" made the compiler branch around one load per slot, each preceded
+    //     by s_waitcnt vmcnt(0) for the write-after-write on its destination register: every wave
+    //     drained the whole prologue-vector fetch before it could request its first weight.)
     const int jo = min(tid >> 4, MT - 1);
-    bool fin = false;
-    int n_out = 0;
-    _Float16 g_h = (_Float16)0;
-    _Float16 *u_out = nullptr;
-    float *st_out = nullptr;
-    int p_out = 0, tile_out = 0, tile_cnt = 0;
+    int trow_o = trow[0];
+    bool tval_o = tval[0];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        if (j == jo) {
-            const int p = j % NPROJ;
-            const int n_raw = trow[j] + (tid & 15);
-            fin = (tid < MT * 16) && tval[j] && n_raw < PP[p].N;
-            n_out = min(n_raw, PP[p].N - 1);
-            g_h = PP[p].g[n_out];
-            u_out = PP[p].u;
-            st_out = tval[j] ? PP[p].st : nullptr;
-            tile_out = trow[j] >> 4;
-            tile_cnt = min(PP[p].N - trow[j], 16);
-            p_out = p;
-        }
+    for (int j = 1; j < MT; ++j) {
+        trow_o = jo == j ? trow[j] : trow_o;
+        tval_o = jo == j ? tval[j] : tval_o;
     }
+    const int p_out = jo - (jo / NPROJ) * NPROJ;
+    const _Float16 *g_ptr = PP[0].g;
+    _Float16 *u_out = PP[0].u;
+    float *st_sel = PP[0].st;
+    int N_o = PP[0].N;
+#pragma unroll
+    for (int p = 1; p < NPROJ; ++p) {
+        g_ptr = p_out == p ? PP[p].g : g_ptr;
+        u_out = p_out == p ? PP[p].u : u_out;
+        st_sel = p_out == p ? PP[p].st : st_sel;
+        N_o = p_out == p ? PP[p].N : N_o;
+    }
+    const int n_raw = trow_o + (tid & 15);
+    const bool fin = (tid < MT * 16) && tval_o && n_raw < N_o;
+    const int n_out = min(n_raw, N_o - 1);
+    const _Float16 g_h = g_ptr[n_out];
+    float *st_out = tval_o ? st_sel : nullptr;
+    const int tile_out = trow_o >> 4;
     __builtin_amdgcn_sched_barrier(0);
     // 1d. packed weights: items (slot j, chunk wave + 8*ci); out-of-range items re-read a valid one.
-    //     Issued in two groups: the first half now, the second half after the first prologue stage,
-    //     so the waves are not parked in a full memory queue while there is VALU work to do and
-    //     the HBM stream runs underneath the prologue.
+    //     ROLLING ISSUE.  With every CU streaming, one 16-byte load per lane and wave (8 KB per CU,
+    //     2 MB per chip) is already the bandwidth-delay product of the HBM pipe: a wave that issues
+    //     more than ~2 of them at once is parked in the issue of the third until the first returns
+    //     (tools/burst_probe: 6 loads at once = 6 loads one after the other = ~1000 cycles each), and
+    //     while it is parked it cannot run its share of the prologue.  So the loads are dealt out in
+    //     use order: OB_ISSUE0 before the prologue, one more after each prologue stage (they return
+    //     underneath the next stage), the rest inside the MFMA phase OB_ISSUE_WIN loads ahead of use.
+    //     Item order = MFMA order: group g = (slot s, chunk ci) holds the NPROJ projections' loads.
+#ifndef OB_ISSUE0
+#define OB_ISSUE0 2
+#endif
+#ifndef OB_ISSUE_STEP
+#define OB_ISSUE_STEP 1
+#endif
+#ifndef OB_ISSUE_WIN
+#define OB_ISSUE_WIN 2
+#endif
     ob_u32x4 wreg[MT][KV];
-    constexpr int NITEM = MT * KV, NA = (NITEM + 1) / 2;
+    constexpr int NITEM = MT * KV, NG = MS * KV;
+    constexpr int C0 = NITEM < OB_ISSUE0 ? NITEM : OB_ISSUE0;
+    constexpr int C1 = NITEM < C0 + OB_ISSUE_STEP ? NITEM : C0 + OB_ISSUE_STEP;
+    constexpr int C2 = NITEM < C1 + OB_ISSUE_STEP ? NITEM : C1 + OB_ISSUE_STEP;
+    constexpr int C3 = NITEM < C2 + OB_ISSUE_STEP ? NITEM : C2 + OB_ISSUE_STEP;
+    constexpr int C4 = NITEM < C3 + OB_ISSUE_STEP ? NITEM : C3 + OB_ISSUE_STEP;
     auto load_items = [&](int first, int last) {
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             if (it >= first && it < last) {
-                const int j = it / KV, ci = it % KV, p = j % NPROJ;
+                const int g = it / NPROJ, p = it % NPROJ, ci = g % KV, j = (g / KV) * NPROJ + p;
 #ifdef OB_PROFILE_ABLATE
                 if (A.ablate == 2 || A.ablate == 3) { wreg[j][ci] = (ob_u32x4){0x12345678u + lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x55aa55aau}; continue; }
 #endif
@@ -485,9 +537,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
     };
-    load_items(0, NA);
+    load_items(0, C0);
     __builtin_amdgcn_sched_barrier(0);      // nothing above may sink below, no use may rise above
     OB_STAMP(1);
+#define OB_ISSUE(a, b) do { __builtin_amdgcn_sched_barrier(0); load_items(a, b); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     // ---- 2. prologue arithmetic in the reference's op order; fp16 tensor ops are native packed
     //         fp16 instructions (contraction off: every op rounds once, as torch does) -------------
@@ -495,15 +548,13 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     if (PRO == OB_P_PLAIN) {
 #pragma unroll
         for (int v = 0; v < KV; ++v) xh[v] = v0[v];
-        load_items(NA, NITEM);
-        __builtin_amdgcn_sched_barrier(0);
+        OB_ISSUE(C0, C2);
     } else if (PRO == OB_P_SWIGLU) {
         float mg, rg, mu, ru;
         if (PST) {
-            load_items(NA, NITEM);
-            __builtin_amdgcn_sched_barrier(0);
             ob_tiles_combine<KV>(ts0, K, A.ln_eps, lane, mg, rg);
             ob_tiles_combine<KV>(ts1, K, A.ln_eps, lane, mu, ru);
+            OB_ISSUE(C0, C1);
         } else {
             const float c0 = (float)c0h, c1 = (float)c1h;
             ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
@@ -513,11 +564,11 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
             float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
             ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
-            load_items(NA, NITEM);
-            __builtin_amdgcn_sched_barrier(0);
+            OB_ISSUE(C0, C1);
             ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mg, rg);
             ob_ln_stats(s[2], s[3], c1, K, A.ln_eps, mu, ru);
         }
+        OB_STAMP(2);
         const float ng = -mg * rg, nu = -mu * ru;
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
@@ -532,14 +583,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
             xh[v] = sg * up;                                    // act_fn(gate) * up, modeling_bitllama.py:257
         }
+        OB_ISSUE(C1, C2);
     } else {
         ob_half8 hv[KV];
         if (PRO == OB_P_RES_LN_RMS) {
             float mean, rstd;
             if (PST) {
-                load_items(NA, NITEM);
-                __builtin_amdgcn_sched_barrier(0);
                 ob_tiles_combine<KV>(ts0, K, A.ln_eps, lane, mean, rstd);
+                OB_ISSUE(C0, C1);
             } else {
                 const float c0 = (float)c0h;
                 ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
@@ -549,10 +600,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
                 float s[2] = {s2[0] + s2[1], q2[0] + q2[1]};
                 ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
-                load_items(NA, NITEM);
-                __builtin_amdgcn_sched_barrier(0);
+                OB_ISSUE(C0, C1);
                 ob_ln_stats(s[0], s[1], c0, K, A.ln_eps, mean, rstd);
             }
+            OB_STAMP(2);
             const float nmr = -mean * rstd;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
@@ -564,8 +615,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         } else {
 #pragma unroll
             for (int v = 0; v < KV; ++v) hv[v] = v1[v];
-            load_items(NA, NITEM);
-            __builtin_amdgcn_sched_barrier(0);
+            OB_ISSUE(C0, C1);
         }
         // RMSNorm (modeling_bitllama.py:76-81): fp32 variance, x * rsqrt -> fp16, weight * that -> fp16
         float ss[1] = {0.f};
@@ -580,6 +630,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 64);
+        OB_STAMP(3);
+        OB_ISSUE(C1, C2);
         const float rs = __builtin_amdgcn_rsqf(ss[0] * __builtin_amdgcn_rcpf((float)K) + A.rms_eps);
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
@@ -590,7 +642,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             if (blockIdx.x == 0 && A.hres_out && valid[v]) ob_st8<SD>(A.hres_out + vbase[v], hv[v]);
         }
     }
-    OB_STAMP(2);
+    OB_STAMP(4);
 
     if (MATH == 0) {
         // a_p = fp16(x * h_p)  (bitnet.py:113), zero padding up to Kpad
@@ -609,7 +661,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
         // no barrier: chunk (wave + 8*ci) is exactly the elements this wave's lanes hold for vector
         // ci, so every wave reads back only what it wrote itself (LDS ops of one wave are in order)
-        OB_STAMP(4);
+        OB_STAMP(6);
+        OB_ISSUE(C2, NITEM);
 
         // ---- 3. MFMA ---------------------------------------------------------------------------
         ob_float4 acc[MT];
@@ -630,7 +683,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 }
             }
         }
-        OB_STAMP(5);
+        OB_STAMP(8);
         // ---- 4. cross-wave reduction: column 0 (lanes 0,16,32,48 hold rows 4*gq..4*gq+3)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -653,13 +706,12 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
         // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
         if (tid < MT * 16) {
-            const float cnt = (float)tile_cnt;
-            const float sm = ob_row16_sum(fin ? uval : 0.f);
-            const float dv = fin ? uval - sm * __builtin_amdgcn_rcpf(cnt) : 0.f;
+            const float sm = ob_row16_sum(fin ? uval : 0.f);     // st_out is only given when N % 16 == 0: full tiles
+            const float dv = fin ? uval - sm * 0.0625f : 0.f;
             const float m2 = ob_row16_sum(dv * dv);
             if (st_out && (tid & 15) == 0) *reinterpret_cast<ob_float2 *>(st_out + 2 * tile_out) = (ob_float2){sm, m2};
         }
-        OB_STAMP(7);
+        OB_STAMP(10);
     } else {
         // ---- integer path ----------------------------------------------------------------------
         // 2b. a_p = fp16(x * h_p); everything from here to the MFMAs is wave-local: chunk
@@ -678,7 +730,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             ob_u16x2 mx = {0, 0};
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
-                ah[p][v] = ob_quad_transpose(xh[v] * hp[p][v], lane);    // -> strided ownership (see ob_ld8)
+                ah[p][v] = SD ? xh[v] * hp[p][v] : ob_quad_transpose(xh[v] * hp[p][v], lane);    // -> strided ownership (see ob_ld8)
                 const ob_u32x4 bits = __builtin_bit_cast(ob_u32x4, ah[p][v]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d)             // |a| as fp16 bit patterns order like unsigned integers
@@ -688,7 +740,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             e_w[p] = (int)max(m >> 10, 1u) - 15;        // |a| < 2^(e+1) for every element of this wave
             nonfinite[p] = m >= 0x7c00u;                // an Inf / NaN activation: fixed point cannot carry it
         }
-        OB_STAMP(3);
+        OB_STAMP(5);
+        OB_ISSUE(C2, C3);
         // this lane's two bit positions j = 2jp + s: compensation 2^(7-j) (j < 7) or -1 (j = 7) folded
         // into the quantisation scale, v_j = 2^j / -128 as the byte of the S dot product
         const int jp = lane & 3;
@@ -754,18 +807,27 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             auto s32 = __builtin_amdgcn_permlane32_swap((uint32_t)t, (uint32_t)t, false, false);
             sdig[p] = (int)(s32[0] + s32[1]);
         }
-        OB_STAMP(4);
+        OB_STAMP(6);
+        OB_ISSUE(C3, C4);
 
-        // 3. MFMA: for every (chunk, word q, half jh): ONE activation read per projection, then one
-        //    MFMA per slot back to back -- consecutive instructions hit different accumulators, so
-        //    the matrix pipe never waits on itself.  Invalid slots re-run a valid tile (never stored).
+        // 3. MFMA, group by group in issue order: for every (word q, half jh) of group (s, ci) ONE
+        //    activation read per projection, then one MFMA per projection -- consecutive instructions
+        //    hit different accumulators.  Before a group is multiplied the loads OB_ISSUE_WIN items
+        //    ahead of it are issued (the wave has nothing else left to do, so parking in that issue costs
+        //    nothing).  Invalid slots re-run a valid tile (never stored).
         const int cpc = lane & 3;
         ob_i32x4 acc[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[j] = (ob_i32x4){0, 0, 0, 0};
         const char *bq = lds_q + (size_t)(gq * 16 + cpc) * 32;
 #pragma unroll
-        for (int ci = 0; ci < KV; ++ci) {
+        for (int g = 0; g < NG; ++g) {
+            {
+                const int prev = g == 0 ? C4 : ((g * NPROJ + OB_ISSUE_WIN) > C4 ? (g * NPROJ + OB_ISSUE_WIN) : C4);
+                const int want = ((g + 1) * NPROJ + OB_ISSUE_WIN) > C4 ? ((g + 1) * NPROJ + OB_ISSUE_WIN) : C4;
+                if (prev < NITEM) OB_ISSUE(prev < NITEM ? prev : NITEM, want < NITEM ? want : NITEM);
+            }
+            const int s = g / KV, ci = g % KV;
             if (ci < per_tile) {
                 const int ch = wave + ci * OB_DEC_WAVES;
 #pragma unroll
@@ -777,18 +839,22 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                         for (int p = 0; p < NPROJ; ++p)
                             bv[p] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + q * 128 + jh * 16);
 #pragma unroll
-                        for (int j = 0; j < MT; ++j) {
-                            const uint32_t w = wreg[j][ci][q];          // invalid slots re-read a valid tile; never stored
+                        for (int p = 0; p < NPROJ; ++p) {
+                            const int j = s * NPROJ + p;
+                            const uint32_t w = wreg[j][ci][q];
                             ob_i32x4 av;
 #pragma unroll
                             for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
-                            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[j % NPROJ], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[p], acc[j], 0, 0, 0);
                         }
+#ifdef OB_PROFILE_ABLATE
+                        if (g == 0 && q == 0 && jh == 0) OB_STAMP(7);
+#endif
                     }
                 }
             }
         }
-        OB_STAMP(5);
+        OB_STAMP(8);
         // 4. per wave, row and digit c: (S_c - 2 B_c) is exact in int32; one conversion to fp32, scaled
         //    by 2^(8c) / (128 * 2^(22-e)) (powers of two: exact), then a fixed-order fp32 sum over the
         //    4 digits and 8 waves in the finishing thread -- deterministic, error <= a few 2^-24
@@ -804,6 +870,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
         }
         __syncthreads();
+        OB_STAMP(9);
         float uval = 0.f;
         if (fin) {
             const int r = tid & 15;
@@ -819,15 +886,17 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
         // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
         if (tid < MT * 16) {
-            const float cnt = (float)tile_cnt;
-            const float sm = ob_row16_sum(fin ? uval : 0.f);
-            const float dv = fin ? uval - sm * __builtin_amdgcn_rcpf(cnt) : 0.f;
+            const float sm = ob_row16_sum(fin ? uval : 0.f);     // st_out is only given when N % 16 == 0: full tiles
+            const float dv = fin ? uval - sm * 0.0625f : 0.f;
             const float m2 = ob_row16_sum(dv * dv);
             if (st_out && (tid & 15) == 0) *reinterpret_cast<ob_float2 *>(st_out + 2 * tile_out) = (ob_float2){sm, m2};
         }
-        OB_STAMP(7);
+        OB_STAMP(10);
     }
+    OB_STAMP_FLUSH();
 #undef OB_STAMP
+#undef OB_STAMP_FLUSH
+#undef OB_ISSUE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -933,9 +1002,9 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     // barrier), or recomputed from the rows by each workgroup
     float mq, rq, mk, rk, mv, rv;
     if (PST) {
-        ob_tiles_combine_rt(tq, NQ, A.ln_eps, lane, mq, rq);
-        ob_tiles_combine_rt(tk, NK, A.ln_eps, lane, mk, rk);
-        ob_tiles_combine_rt(tv, NK, A.ln_eps, lane, mv, rv);
+        ob_tiles_combine_rt(tq, A.st_q, NQ, A.ln_eps, lane, mq, rq);
+        ob_tiles_combine_rt(tk, A.st_k, NK, A.ln_eps, lane, mk, rk);
+        ob_tiles_combine_rt(tv, A.st_v, NK, A.ln_eps, lane, mv, rv);
     } else {
         const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1134,9 +1203,9 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(con
     if (A.st_q) {                                            // producer's tile partials (uniform branch)
         ObTileStatsRt tq, tk, tv;
         ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane);
-        ob_tiles_combine_rt(tq, NQ, A.ln_eps, lane, mq, rq);
-        ob_tiles_combine_rt(tk, NK, A.ln_eps, lane, mk, rk);
-        ob_tiles_combine_rt(tv, NK, A.ln_eps, lane, mv, rv);
+        ob_tiles_combine_rt(tq, A.st_q, NQ, A.ln_eps, lane, mq, rq);
+        ob_tiles_combine_rt(tk, A.st_k, NK, A.ln_eps, lane, mk, rk);
+        ob_tiles_combine_rt(tv, A.st_v, NK, A.ln_eps, lane, mv, rv);
     } else {
         const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1359,7 +1428,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_lmhead_kernel(const ObH
         if (A.st_prev) {
             ObTileStatsRt tp;
             ob_tiles_load_rt(tp, A.st_prev, K, lane);
-            ob_tiles_combine_rt(tp, K, A.ln_eps, lane, mean, rstd);
+            ob_tiles_combine_rt(tp, A.st_prev, K, A.ln_eps, lane, mean, rstd);
         } else {
             ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
             ob_ln_stats(s[0], s[1], c, K, A.ln_eps, mean, rstd);

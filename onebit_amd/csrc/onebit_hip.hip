@@ -11,6 +11,7 @@
 #include "ob_linear.h"
 #include "ob_pack.h"
 #include "ob_decode.h"
+#include "ob_decode2.h"
 #include "ob_gemm.h"
 #include "ob_skinny.h"
 #include "ob_batch.h"
@@ -389,7 +390,7 @@ static int ob_cu_count()
 
 static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *name, float *st = nullptr)
 {
-    d.st = st;
+    d.st = (s.N % 16 == 0) ? st : nullptr;      // tile partials exist for whole 16-row tiles only
     if (!s.weight || !s.input_factor || !s.weight_scale || !u)
         return ob_fail(ONEBIT_E_ARG, "decode_step: null pointer in projection %s", name);
     if (s.K % 32 != 0 || s.ldw_bytes % 4 != 0 || s.ldw_bytes < s.K / 8 || s.N <= 0)
@@ -438,6 +439,49 @@ static bool ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStre
     return true;
 }
 
+// ---- role-split kernel (ob_decode2.h): 1024 threads, prologue waves + matrix waves ----
+template <int KV, int MS, int PRO, int NPROJ, bool PST>
+static void ob_launch_dec_gemv2_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_dec_gemv2_kernel<KV, MS, PRO, NPROJ, PST>, attr_set, 160 * 1024);
+    hipLaunchKernelGGL((ob_dec_gemv2_kernel<KV, MS, PRO, NPROJ, PST>), dim3(G), dim3(OB_DEC2_THREADS), lds, s, a);
+}
+template <int KV, int MS, int PRO, int NPROJ>
+static void ob_launch_dec_gemv2_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    // KV = 4 (in_features > 12288): the tile partials of four 256-tile blocks per vector do not fit the
+    // 128-register budget of a 1024-thread workgroup next to the vectors themselves: recompute there
+    if constexpr (PRO == OB_P_RES_LN_RMS && KV < 4) {
+        if (a.st_prev) return ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, true>(a, G, lds, s);
+    }
+    if constexpr (PRO == OB_P_SWIGLU && KV < 4) {
+        if (a.st_gate && a.st_up) return ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, true>(a, G, lds, s);
+    }
+    ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, false>(a, G, lds, s);
+}
+template <int KV, int MS>
+static bool ob_launch_dec_gemv2_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    if (a.prologue == OB_P_PLAIN && a.nproj == 1) ob_launch_dec_gemv2_t<KV, MS, OB_P_PLAIN, 1>(a, G, lds, s);
+    else if (a.prologue == OB_P_SWIGLU && a.nproj == 1) ob_launch_dec_gemv2_t<KV, MS, OB_P_SWIGLU, 1>(a, G, lds, s);
+    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 2) ob_launch_dec_gemv2_t<KV, MS, OB_P_RES_LN_RMS, 2>(a, G, lds, s);
+    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 3) ob_launch_dec_gemv2_t<KV, MS, OB_P_RES_LN_RMS, 3>(a, G, lds, s);
+    else if (a.prologue == OB_P_EMBED_RMS && a.nproj == 3) ob_launch_dec_gemv2_t<KV, MS, OB_P_EMBED_RMS, 3>(a, G, lds, s);
+    else return false;
+    return true;
+}
+// OB_DEC2=1 sends the integer-path launches through the role-split kernel, OB_DEC2=2 the single-chunk
+// launches (o_proj) as well.  Default 0: on the 7B shapes the single-role kernel measures faster
+// (whole token 975 vs 909 tok/s) -- the prologue chain, not the weight stream, is
+// the long pole, and eight prologue waves run it no faster than eight combined waves.
+static int ob_dec2_mode()
+{
+    static int m = -1;
+    if (m < 0) { const char *e = getenv("OB_DEC2"); m = e ? atoi(e) : 0; }
+    return m;
+}
+
 // OB_DECODE_MATH=f16 selects the fp16 sign-expansion kernels for A/B measurements; default is the
 // integer path wherever its alignment requirement holds.
 static int ob_decode_math()
@@ -467,7 +511,7 @@ extern "C" int onebit_debug_read_timing(unsigned long long *host_out, int nblock
 {
     if (!g_dbg) return -1;
     (void)hipDeviceSynchronize();
-    return (int)hipMemcpy(host_out, g_dbg, (size_t)nblocks * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(host_out, g_dbg, (size_t)nblocks * 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -477,7 +521,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     a.ablate = ob_ablate_mode();
 #ifdef OB_PROFILE_ABLATE
     if (getenv("OB_TIMING")) {
-        if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 64 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 64 * sizeof(unsigned long long)); }
+        if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 128 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 128 * sizeof(unsigned long long)); }
         a.dbg = g_dbg;
     }
 #endif
@@ -494,7 +538,8 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
     // one workgroup per CU when a projection has more tiles than that
     const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);      // KV 3, 4: one slot
-    int G = ob_cu_count();
+    static const int wgs_per_cu = getenv("OB_DEC_WGS_PER_CU") ? atoi(getenv("OB_DEC_WGS_PER_CU")) : 1;   // A/B switch
+    int G = ob_cu_count() * (wgs_per_cu > 0 ? wgs_per_cu : 1);
     if (max_tiles < G) G = max_tiles;
     if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
     const int MS = (max_tiles + G - 1) / G;
@@ -502,6 +547,17 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
     const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2);
+    {   // role-split kernel for the integer path
+        const size_t lds2 = (size_t)a.nproj * Kpad * 4 + (size_t)MT * 8 * 64 * 4 + 32 * 4 + 8 * 3 * 8 * 4 + 32 * 4;
+        const int mode = ob_dec2_mode();
+        if (aligned && ob_decode_math() == 1 && lds2 <= 160 * 1024 && mode && (use_i8 || mode == 2)) {
+            bool ok2 = false, hit2 = false;
+#define OB_CASE2(P, M) if (!hit2 && KV == P && MS == M) { hit2 = true; ok2 = ob_launch_dec_gemv2_p<P, M>(a, G, lds2, s); }
+            OB_CASE2(1, 1) OB_CASE2(1, 2) OB_CASE2(1, 3) OB_CASE2(1, 4) OB_CASE2(2, 1) OB_CASE2(2, 2) OB_CASE2(3, 1) OB_CASE2(4, 1)
+#undef OB_CASE2
+            if (hit2 && ok2) return ob_launch_status("decode gemv (role-split)");
+        }
+    }
     const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
     if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
     bool ok = false, hit = false;
@@ -751,6 +807,8 @@ extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, 
         if ((rc = ob_fill_proj(a.p[p], projs[p], outs[p], "fused", in->st_out[p]))) return rc;
     }
     a.st_prev = in->st_prev; a.st_gate = in->st_gate; a.st_up = in->st_up;
+    if (a.K % 16 != 0 && (a.st_prev || a.st_gate || a.st_up))
+        return ob_fail(ONEBIT_E_SHAPE, "fused_gemv: tile statistics need in_features %% 16 == 0");
     for (const float *sp : {a.st_prev, a.st_gate, a.st_up, (const float *)in->st_out[0], (const float *)in->st_out[1], (const float *)in->st_out[2]})
         if (sp && !ob_aligned(sp, 16)) return ob_fail(ONEBIT_E_ALIGN, "fused_gemv: tile statistics must be 16-byte aligned");
     a.xin = (const _Float16 *)in->xin; a.embed = (const _Float16 *)in->embed; a.token = in->token;
@@ -791,6 +849,8 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     float *ts = st->tile_stats;
     float *ts_q = ts + sl.off[0], *ts_k = ts + sl.off[1], *ts_v = ts + sl.off[2], *ts_o = ts + sl.off[3],
           *ts_gate = ts + sl.off[4], *ts_up = ts + sl.off[5], *ts_down = ts + sl.off[6];
+    if ((m->n_heads * D) % 16 || (m->n_kv_heads * D) % 16 || H % 16 || I % 16)      // partial tiles: every consumer
+        ts_q = ts_k = ts_v = ts_o = ts_gate = ts_up = ts_down = nullptr;             // recomputes its statistics
     int rc;
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];

@@ -220,3 +220,33 @@ class COracle:
         if rc:
             raise ValueError(f"rc={rc}")
         return y.reshape(*lead, N)
+
+
+# ------------------------------------------------------ torch-ops CPU port ---
+# The reference's CPU path is made of ATen ops (broadcast shift over int64 temporaries, a dense
+# matmul, an in-place scale, LayerNorm), and ATen parallelises each of them over the host cores.
+# These two functions restate that op sequence (bitnet.py:98-118) with the same torch ops so the
+# benchmark can time it with `torch.set_num_threads(os.cpu_count())`, and the
+# "unpack once" variant that keeps the dense matrix between calls (what any sane CPU deployment
+# would do; it shows how much of the reference's time is re-unpacking).  Test infrastructure /
+# bench cpu_baseline only -- never imported by onebit_amd.
+
+def torch_unpack_ref_style(packed, dtype):
+    """bitnet.py:98-110 with torch ops: bit_k = (byte >> k) & 1 broadcast over a trailing axis of 8,
+    -> dtype, flatten, w = 1 - 2 * bit."""
+    import torch
+    k = torch.arange(8, device=packed.device).reshape(1, 1, 8)
+    bits = torch.bitwise_and(torch.bitwise_right_shift(packed[:, :, None], k), 1).to(dtype)
+    return 1 - 2 * bits.reshape(packed.shape[0], packed.shape[1] * 8)
+
+
+def torch_forward_ref_style(packed, x, h, g, eps=1e-5, dense=None):
+    """bitnet.py:112-118 with torch ops; `dense` = a cached result of torch_unpack_ref_style turns the
+    call into the unpack-once variant."""
+    import torch
+    import torch.nn.functional as F
+    a = x * h.reshape(1, -1)
+    w = torch_unpack_ref_style(packed, g.dtype) if dense is None else dense
+    out = F.linear(a, w)
+    out = out * g.reshape(1, -1)
+    return F.layer_norm(out, (out.shape[-1],), eps=eps)

@@ -10,6 +10,9 @@ if os.environ.get("OB_PROFILE_BUILD"):     # profiling build (-DOB_PROFILE_ABLAT
                            "-DOB_PROFILE_ABLATE", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
                            os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
     _lib.LIB_PATH = so
+if os.environ.get("OB_LIB"):
+    from onebit_amd import _lib
+    _lib.LIB_PATH = os.environ["OB_LIB"]
 from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
 from onebit_amd.engine import fused_gemv, tile_stats_floats, PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU
 USE_STATS = os.environ.get("OB_PROBE_STATS", "1") == "1"      # producers' tile partials (the decode_step path)
