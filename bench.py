@@ -10,15 +10,27 @@ reference's layout, resident in HBM before timing.  For N > 1 every rank decodes
 sequence on its own full replica (decode does not shard, BASELINE.json north_star: "decode
 stays single-GPU") -- weak scaling, no data-path collective; `value` is the aggregate.
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU over RCCL); launched by
+torchrun directly it uses the ranks it is given.  Either way it refuses to report n_gpus != the
+RCCL world size.
+
 The JSON line also carries
-  roofline     -- the dominant kernel (the 4096->11008 1-bit GEMV) timed with HIP events over
-                  >= 64 distinct weight sets (> 256 MB Infinity Cache), algorithmic bytes / time
-                  against the 8 TB/s HBM peak
-  cpu_baseline -- the oracle's reference-style CPU path (unpack every call) timed on this host
+  roofline     -- the TIME-dominant kernel of the decode step (one of the four fused 1-bit GEMV
+                  launches of a layer), each timed with HIP events over the 32 layers' own weights
+                  (> 256 MB Infinity Cache), algorithmic bytes / time against the 8 TB/s HBM peak;
+                  `per_kernel` lists all four, `whole_token` the fraction of the complete step
+  cpu_baseline -- the oracle's reference-style CPU path (unpack every call) timed on this host: one
+                  core (C port), all cores (the reference's own ATen op sequence) and the same with
+                  the dense matrix unpacked once
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,6 +40,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+
+
+def csrc_sha():
+    """Hash of the kernel sources: stamps PMC-derived numbers so a stale file is never reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "onebit_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_command(gpus, argv, port=None):
+    """The torchrun command `bench.py --gpus N` re-executes itself under when it was started as a
+    plain process (one rank per GPU, rendezvous on 127.0.0.1)."""
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def parse():
@@ -73,62 +107,126 @@ def token_bytes(cfg, ctx):
     return star, star + lm_head + kv
 
 
-def measure_roofline(model, dev):
-    """Dominant kernel of the decode step: the fused gate+up 1-bit GEMV launch (hidden ->
-    2 x intermediate, T = 1: residual + LayerNorm + RMSNorm prologue, two projections), exactly the
-    launch onebit_decode_step issues.  One launch per decoder layer over that layer's own weights
-    (7B: 32 distinct sets = 361 MB, beyond the 256 MB Infinity Cache), captured in a HIP graph and
-    replayed; HIP events on the replay stream.  The per-launch time therefore includes the
-    dependent-kernel boundary (~1.3 us) that every launch of a decode chain pays; rocprofv3's
-    kernel-only duration is in profiles/."""
-    from onebit_amd.engine import PRO_RES_LN_RMS, fused_gemv
-    cfg = model.config
-    K, N = cfg.hidden_size, cfg.intermediate_size
-    f16 = torch.float16
-    hres = torch.randn(K, device=dev).to(f16)
-    u_prev = torch.randn(K, device=dev).to(f16)
-    hres_out = torch.empty(K, device=dev, dtype=f16)
-    ug, uu = torch.empty(N, device=dev, dtype=f16), torch.empty(N, device=dev, dtype=f16)
-    layers = list(model.model.layers)
-
-    def chain():
-        for layer in layers:
-            fused_gemv([layer.mlp.gate_proj, layer.mlp.up_proj], [ug, uu], PRO_RES_LN_RMS,
-                       rms_eps=cfg.rms_norm_eps, hres_in=hres, u_prev=u_prev, hres_out=hres_out,
-                       rms_w=layer.post_attention_layernorm.weight)
-
-    chain()
+def _chain_us(launch_layer, layers, dev, min_launches=512):
+    """us per launch of `launch_layer(layer)` captured once per decoder layer (distinct weights) in a
+    HIP graph and replayed; HIP events on the replay stream.  Includes the dependent-kernel boundary
+    every launch of a decode chain pays."""
+    for layer in layers:
+        launch_layer(layer)
     torch.cuda.synchronize(dev)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        chain()
+        for layer in layers:
+            launch_layer(layer)
     for _ in range(8):                      # settle clocks / TLBs on the new buffers before timing
         graph.replay()
     torch.cuda.synchronize(dev)
-    reps = max(2, 512 // len(layers))
+    reps = max(2, min_launches // len(layers))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         graph.replay()
     e1.record()
     torch.cuda.synchronize(dev)
-    n = reps * len(layers)
-    us = e0.elapsed_time(e1) * 1e3 / n
-    ab = 2 * algorithmic_bytes(1, K, N)
-    achieved = ab / (us * 1e-6) / 1e9
-    traffic = None
+    return e0.elapsed_time(e1) * 1e3 / (reps * len(layers)), reps * len(layers)
+
+
+def measure_roofline(model, dev, ms_per_token, tok_bytes):
+    """The four fused 1-bit GEMV launches of a decoder layer, exactly as onebit_decode_step issues
+    them (prologues, producers' tile partials), each as a chain over the layers' own weights.  The
+    `roofline` object is the one that takes the most time per token; `per_kernel` lists all four;
+    attention + lm_head + argmax are the remainder of the measured step."""
+    from onebit_amd.engine import PRO_PLAIN, PRO_RES_LN_RMS, PRO_SWIGLU, fused_gemv, tile_stats_floats
+    cfg = model.config
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    f16 = torch.float16
+    rn = lambda n: torch.randn(n, device=dev).to(f16)
+    hres, u_prev, attn = rn(H), rn(H), rn(H)
+    ug_in, uu_in = rn(I), rn(I)
+    hout = torch.empty(H, device=dev, dtype=f16)
+    o = {k: torch.empty(n, device=dev, dtype=f16) for k, n in dict(q=H, k=H, v=H, o=H, g=I, u=I, d=H).items()}
+    st = {k: torch.zeros(tile_stats_floats(n), device=dev) for k, n in dict(h=H, q=H, k=H, v=H, o=H, g=I, u=I, d=H, gi=I, ui=I).items()}
+    layers = list(model.model.layers)
+    L = len(layers)
+    ab = algorithmic_bytes
+    kinds = {
+        "qkv": (lambda l: fused_gemv([l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj], [o["q"], o["k"], o["v"]],
+                                     PRO_RES_LN_RMS, rms_eps=cfg.rms_norm_eps, hres_in=hres, u_prev=u_prev, hres_out=hout,
+                                     rms_w=l.input_layernorm.weight, st_prev=st["h"], stats_out=[st["q"], st["k"], st["v"]]),
+                3 * ab(1, H, H), "residual + LayerNorm + RMSNorm prologue, q|k|v, %d->3x%d" % (H, H)),
+        "o": (lambda l: fused_gemv([l.self_attn.o_proj], [o["o"]], PRO_PLAIN, xin=attn, stats_out=[st["o"]]),
+              ab(1, H, H), "o_proj %d->%d" % (H, H)),
+        "gate_up": (lambda l: fused_gemv([l.mlp.gate_proj, l.mlp.up_proj], [o["g"], o["u"]], PRO_RES_LN_RMS,
+                                         rms_eps=cfg.rms_norm_eps, hres_in=hres, u_prev=u_prev, hres_out=hout,
+                                         rms_w=l.post_attention_layernorm.weight, st_prev=st["h"], stats_out=[st["g"], st["u"]]),
+                    2 * ab(1, H, I), "residual + LayerNorm + RMSNorm prologue, gate|up, %d->2x%d" % (H, I)),
+        "down": (lambda l: fused_gemv([l.mlp.down_proj], [o["d"]], PRO_SWIGLU, u_gate=ug_in, u_up=uu_in,
+                                      st_gate=st["gi"], st_up=st["ui"], stats_out=[st["d"]]),
+                 ab(1, I, H), "SiLU(LayerNorm(gate)) * LayerNorm(up) prologue, down %d->%d" % (I, H)),
+    }
+    # tile partials the prologues read: produce them once from the synthetic inputs
+    fused_gemv([layers[0].self_attn.o_proj], [o["o"]], PRO_PLAIN, xin=attn, stats_out=[st["h"]])
+    u_prev.copy_(o["o"])
+    fused_gemv([layers[0].mlp.gate_proj, layers[0].mlp.up_proj], [o["g"], o["u"]], PRO_RES_LN_RMS, rms_eps=cfg.rms_norm_eps,
+               hres_in=hres, u_prev=u_prev, hres_out=hout, rms_w=layers[0].post_attention_layernorm.weight, st_prev=st["h"],
+               stats_out=[st["gi"], st["ui"]])
+    ug_in.copy_(o["g"]); uu_in.copy_(o["u"])
+    traffic = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("ob_dec_gemv_gateup_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("csrc_sha") == csrc_sha():
+                traffic = tj.get("bytes_per_launch", {})
         except Exception:
-            traffic = None
-    return {"bound": "hbm", "kernel": "ob_dec_gemv_kernel<KV=%d,MS,aligned,RES_LN_RMS,i8,NPROJ=2> (fused gate+up 1-bit GEMV %d->2x%d, T=1)" % ((K + 4095) // 4096, K, N),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(us, 3), "launches": n,
-            "distinct_weight_sets": len(layers),
-            "note": "HIP events around graph replays of back-to-back launches: includes the kernel boundary"}
+            traffic = {}
+    per = []
+    for name, (fn, nbytes, what) in kinds.items():
+        us, n = _chain_us(fn, layers, dev)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        per.append({"kernel": name, "what": what, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 3),
+                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "us_per_token": round(us * L, 1),
+                    "traffic": traffic.get(name), "launches": n})
+    dom = max(per, key=lambda r: r["us_per_token"])
+    gemv_us = sum(r["us_per_token"] for r in per)
+    whole = tok_bytes / (ms_per_token * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ob_dec_gemv_kernel: %s (%s), T=1" % (dom["kernel"], dom["what"]),
+            "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
+            "launches": dom["launches"], "distinct_weight_sets": L, "selection": "largest time per token of the four GEMV launches",
+            "per_kernel": per,
+            "whole_token": {"algorithmic_bytes": tok_bytes, "ms": round(ms_per_token, 4), "achieved": round(whole, 1),
+                            "frac": round(whole / HBM_PEAK_GBS, 4),
+                            "gemv_launches_us": round(gemv_us, 1),
+                            "attention_lm_head_argmax_us": round(ms_per_token * 1e3 - gemv_us, 1)},
+            "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, same kernel sources)" if traffic
+                               else "none for these kernel sources (profiles/pmc_traffic.json is stamped with another csrc_sha)"),
+            "note": "HIP events around graph replays of back-to-back launches: includes the ~1.7 us kernel boundary"}
+
+
+def _timed(fn, dev, world, warm=6, iters=20):
+    """Per-iteration HIP-event times of fn() (>= 20 iterations after `warm` warm-ups): returns
+    (median_s, min_s) of the slowest rank's figures."""
+    import torch.distributed as dist
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    ts = [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(iters)]
+    med, mn = statistics.median(ts), min(ts)
+    if world > 1:
+        t = torch.tensor([med, mn], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med, mn = float(t[0]), float(t[1])
+    return med, mn
 
 
 def measure_prefill_sharded(cfg, dev, world, rank):
@@ -145,29 +243,18 @@ def measure_prefill_sharded(cfg, dev, world, rank):
     gs = (0.1 * (0.5 + torch.rand(N, generator=g, device=dev))).half()
     x = torch.randn(T, K, generator=g, device=dev).half()
     shard = shard_k(W, h, gs, None, rank, world)
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    flops = 2.0 * T * K * N
 
-    for _ in range(6):                      # the first calls after the decode phase run at ramping clocks
-        k_sharded_forward(shard, x, mode="rs_ag")
-    fence()
-    n = 12
-    t0 = time.perf_counter()
-    for _ in range(n):
-        k_sharded_forward(shard, x, mode="rs_ag")
-    fence()
-    dt = (time.perf_counter() - t0) / n
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    res = {"layer": "%d->%d" % (K, N), "tokens": T, "k_shards": world, "exchange": "reduce_scatter(fp32)+all_gather(fp16)",
-           "ms_per_call": round(dt * 1e3, 3), "tokens_per_s": round(T / dt, 1),
-           "TFLOPs": round(2.0 * T * K * N / dt / 1e12, 1), "mfma_peak_TFLOPs": 2500.0 * world,
-           "frac_of_mfma_peak": round(2.0 * T * K * N / dt / 1e12 / (2500.0 * world), 4)}
+    def entry(dt, dmin, **kw):
+        d = {"ms_per_call": round(dt * 1e3, 3), "ms_min": round(dmin * 1e3, 3), "iterations": 20,
+             "tokens_per_s": round(T / dt, 1), "TFLOPs": round(flops / dt / 1e12, 1), "TFLOPs_best": round(flops / dmin / 1e12, 1),
+             "frac_of_mfma_peak": round(flops / dt / 1e12 / (2500.0 * world), 4)}
+        d.update(kw)
+        return d
+
+    dt, dmin = _timed(lambda: k_sharded_forward(shard, x, mode="rs_ag"), dev, world)
+    res = entry(dt, dmin, layer="%d->%d" % (K, N), tokens=T, k_shards=world, exchange="reduce_scatter(fp32)+all_gather(fp16)",
+                mfma_peak_TFLOPs=2500.0 * world, timing="median of 20 HIP-event-timed calls (slowest rank)")
     # the layout that needs no exchange at all: the packed matrix is only N*K/8 bytes, so every rank
     # keeps all of it and takes T/world tokens (token sharding); reported beside the K-sharded path
     from onebit_amd import BitLinearInf
@@ -175,43 +262,17 @@ def measure_prefill_sharded(cfg, dev, world, rank):
     m.weight.data, m.input_factor.data, m.weight_scale.data = W, h, gs
     Tl = T // world
     xl = x[rank * Tl:(rank + 1) * Tl]
-    for _ in range(6):
-        m(xl)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        m(xl)
-    fence()
-    dt2 = (time.perf_counter() - t0) / n
-    if world > 1:
-        tmax = torch.tensor([dt2], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt2 = float(tmax.item())
-    # N-sharded (output rows split): only the LayerNorm statistics cross ranks (2 all-reduces of [T] fp32)
+    dt2, dmin2 = _timed(lambda: m(xl), dev, world)
+    # N-sharded (output rows split): only the LayerNorm statistics cross ranks (one all-gather of [T, 2] fp32)
     try:
         from onebit_amd.sharded import n_sharded_forward, shard_n
         nsh = shard_n(W, h, gs, None, rank, world)
-        for _ in range(4):
-            n_sharded_forward(nsh, x)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            n_sharded_forward(nsh, x)
-        fence()
-        dt3 = (time.perf_counter() - t0) / n
-        if world > 1:
-            tmax = torch.tensor([dt3], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt3 = float(tmax.item())
-        res["n_sharded"] = {"rows_per_rank": nsh.n1 - nsh.n0, "exchange": "all_gather(fp32 [T,2] row statistics); output stays N-sharded",
-                            "ms_per_call": round(dt3 * 1e3, 3), "tokens_per_s": round(T / dt3, 1),
-                            "TFLOPs": round(2.0 * T * K * N / dt3 / 1e12, 1),
-                            "frac_of_mfma_peak": round(2.0 * T * K * N / dt3 / 1e12 / (2500.0 * world), 4)}
+        dt3, dmin3 = _timed(lambda: n_sharded_forward(nsh, x), dev, world, warm=4)
+        res["n_sharded"] = entry(dt3, dmin3, rows_per_rank=nsh.n1 - nsh.n0,
+                                 exchange="all_gather(fp32 [T,2] row statistics); output stays N-sharded")
     except Exception as e:
         res["n_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    res["token_sharded"] = {"tokens_per_rank": Tl, "ms_per_call": round(dt2 * 1e3, 3), "tokens_per_s": round(Tl * world / dt2, 1),
-                            "TFLOPs": round(2.0 * Tl * world * K * N / dt2 / 1e12, 1),
-                            "frac_of_mfma_peak": round(2.0 * Tl * world * K * N / dt2 / 1e12 / (2500.0 * world), 4)}
+    res["token_sharded"] = entry(dt2, dmin2, tokens_per_rank=Tl)
     return res
 
 
@@ -279,20 +340,15 @@ def measure_prefill_model(model, dev, B=8, S=2048):
     model.set_attention("sdpa").set_fused_glue(True)
     try:
         with torch.no_grad():
-            model(ids[:1, :128]); model(ids)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            n = 2
-            for _ in range(n):
-                model(ids)
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / n
+            model(ids[:1, :128])
+            dt, dmin = _timed(lambda: model(ids), dev, 1, warm=2, iters=20)
     finally:
         model.set_attention("eager").set_fused_glue(False)
         torch.cuda.empty_cache()
     H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     w1 = L * (4 * H * H + 3 * H * I)
-    return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "tokens_per_s": round(B * S / dt, 1),
+    return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "ms_min": round(dmin * 1e3, 1), "iterations": 20,
+            "tokens_per_s": round(B * S / dt, 1),
             "onebit_layer_TFLOPs_equivalent": round(2.0 * B * S * w1 / dt / 1e12, 1),
             "attention": "sdpa", "glue": "onebit_rows_res_ln_rms + onebit_rows_swiglu", "per": "GPU"}
 
@@ -325,23 +381,62 @@ def measure_cpu_baseline(cfg):
         nlayers += 1
     total /= nlayers
     tok_s = 1.0 / (total * cfg.num_hidden_layers)
-    return {"value": round(tok_s, 5), "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": "%d decoder layers' worth of 1-bit projections (7 BitLinearInf calls each, T=1) through the C "
-                      "restatement of the reference's unpack-every-call forward, %.2f s per layer; extrapolated to %d "
-                      "layers (glue ops and lm_head not included)" % (nlayers, total, cfg.num_hidden_layers),
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(tok_s, 5), "unit": "tokens/s", "cores": 1, "kind": "port",
+           "sample": "%d decoder layers' worth of 1-bit projections (7 BitLinearInf calls each, T=1) through the C "
+                     "restatement of the reference's unpack-every-call forward, %.2f s per layer; extrapolated to %d "
+                     "layers (glue ops and lm_head not included)" % (nlayers, total, cfg.num_hidden_layers),
+           "host_cpus": os.cpu_count()}
+    # the reference's own op sequence (ATen ops, bitnet.py:98-118) on ALL host cores, and
+    # the same with the dense matrix unpacked once and kept (oracle/oracle.py, torch-ops port)
+    try:
+        from oracle.oracle import torch_forward_ref_style, torch_unpack_ref_style
+        ncpu = os.cpu_count() or 1
+        old = torch.get_num_threads()
+        torch.set_num_threads(ncpu)
+        tl = [(torch.from_numpy(p), torch.from_numpy(x), torch.from_numpy(h), torch.from_numpy(g)) for (_, _, p, x, h, g) in layers]
+        def one_layer(dense=None):
+            t0 = time.perf_counter()
+            for i, (p, x, h, g) in enumerate(tl):
+                torch_forward_ref_style(p, x, h, g, dense=None if dense is None else dense[i])
+            return time.perf_counter() - t0
+        one_layer()                                         # warm the thread pool / allocator
+        ts, spent = [], 0.0
+        while len(ts) < 3 and spent < 10.0:
+            t = one_layer(); ts.append(t); spent += t
+        t_all = min(ts)
+        dense = [torch_unpack_ref_style(p, torch.float32) for (p, _, _, _) in tl]
+        one_layer(dense)
+        t_once = min(one_layer(dense) for _ in range(5))
+        torch.set_num_threads(old)
+        out["all_cores"] = {"value": round(1.0 / (t_all * cfg.num_hidden_layers), 5), "unit": "tokens/s", "cores": ncpu,
+                            "kind": "port (the reference's ATen op sequence: int64 broadcast unpack on every call, F.linear, *g, LayerNorm)",
+                            "sample": "one decoder layer's 7 projections, best of %d, %.3f s per layer, x %d layers" % (len(ts), t_all, cfg.num_hidden_layers)}
+        out["unpack_once"] = {"value": round(1.0 / (t_once * cfg.num_hidden_layers), 5), "unit": "tokens/s", "cores": ncpu,
+                              "kind": "port, dense fp32 +-1 matrix unpacked once and cached (what the reference does NOT do)",
+                              "sample": "one decoder layer's 7 projections, best of 5, %.4f s per layer, x %d layers" % (t_once, cfg.num_hidden_layers)}
+    except Exception as e:                                   # the single-core figure must survive
+        out["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process: launch the N ranks ourselves (their rank 0 prints the JSON line)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:]), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE {world}; refusing to report a "
+                         "rank count that was not measured")
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        rccl_ranks = dist.get_world_size()
+        assert rccl_ranks == args.gpus, (rccl_ranks, args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -399,19 +494,14 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:      # right after the decode phase: same thermal / clock state as the headline
-        roof = measure_roofline(model, dev)
+        ctx0 = args.prompt + args.warmup + args.steps // 2
+        roof = measure_roofline(model, dev, dt / args.steps * 1e3, token_bytes(cfg, ctx0)[1])
     prefill = None
     if not args.no_prefill:
         try:
             prefill = measure_prefill_sharded(cfg, dev, world, rank)
         except Exception as e:              # the decode line must survive a failure of the secondary measurement
             prefill = {"error": "%s: %s" % (type(e).__name__, e)}
-    ksd = None
-    if args.k_sharded_decode:
-        try:
-            ksd = measure_k_sharded_decode(cfg, dev, world, rank, min(args.steps, 16), args.prompt)
-        except Exception as e:
-            ksd = {"error": "%s: %s" % (type(e).__name__, e)}
     serve = None
     if not args.no_serve and rank == 0:
         try:
@@ -424,6 +514,19 @@ def main():
             pmodel = measure_prefill_model(model, dev)
         except Exception as e:
             pmodel = {"error": "%s: %s" % (type(e).__name__, e)}
+    ksd = None
+    if args.k_sharded_decode or world > 1:      # BASELINE config 4 whenever there is more than one rank: LLaMA-13B shapes
+        try:
+            del stepper
+            model_13 = model_config("13b") if world > 1 else cfg
+            if world > 1:
+                del model
+                model = None
+                torch.cuda.empty_cache()
+            ksd = measure_k_sharded_decode(model_13, dev, world, rank, min(args.steps, 16), args.prompt)
+            ksd["model"] = "LLaMA-13B shapes" if world > 1 else "LLaMA-%s shapes" % args.model.upper()
+        except Exception as e:
+            ksd = {"error": "%s: %s" % (type(e).__name__, e)}
     cpu = None
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
@@ -444,7 +547,8 @@ def main():
             "config": {"workload": "LLaMA-%s OneBit greedy decode, batch=1 per GPU, prompt %d, synthetic "
                                    "inference checkpoint (reference layout), whole token incl. attention + lm_head"
                                    % (args.model.upper(), args.prompt),
-                       "engine": engine, "replicas": world},
+                       "engine": engine, "replicas": world, "rccl_ranks": rccl_ranks,
+                       "launcher": "torch.distributed.run (one rank per GPU)" if world > 1 else "single process"},
             "token_hbm": {"algorithmic_bytes_per_token": tok_b, "onebit_layer_bytes_per_token": star_b,
                           "achieved_GBps_whole_token": round(tok_b * per_gpu_tok_s / 1e9, 1),
                           "frac_of_8TBps": round(tok_b * per_gpu_tok_s / 1e9 / HBM_PEAK_GBS, 4)},
