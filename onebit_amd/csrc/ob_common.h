@@ -15,6 +15,10 @@ typedef int32_t ob_i32x4 __attribute__((ext_vector_type(4)));
 
 #define OB_WAVE 64
 
+#if defined(OB_PROFILE_ABLATE) && !defined(OB_PROFILE_STAMPS)
+#define OB_PROFILE_STAMPS 1      // the ablation build carries the phase timestamps too
+#endif
+
 // Wave64 reductions on the DPP network (row = 16 lanes): quad butterflies, row mirrors, then the two
 // row broadcasts; ~8 VALU instructions, no LDS crossbar traffic (ds_bpermute-based shuffles cost
 // ~100 cycles per step).  Every lane receives the result.

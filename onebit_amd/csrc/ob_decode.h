@@ -392,6 +392,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;              // launch floor
+#endif
+#ifdef OB_PROFILE_STAMPS
     // phase timestamps stay in registers and are written once at the end (a store per stamp would sit
     // in the same vmcnt queue as the loads being measured)
     unsigned long long stamp_[16] = {};
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                             for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
                             acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[p], acc[j], 0, 0, 0);
                         }
-#ifdef OB_PROFILE_ABLATE
+#ifdef OB_PROFILE_STAMPS
                         if (g == 0 && q == 0 && jh == 0) OB_STAMP(7);
 #endif
                     }

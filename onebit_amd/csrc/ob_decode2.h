@@ -66,6 +66,8 @@ __global__ __launch_bounds__(OB_DEC2_THREADS) void ob_dec_gemv2_kernel(const ObG
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;
+#endif
+#ifdef OB_PROFILE_STAMPS
     unsigned long long stamp_[16] = {};
 #define OB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define OB_STAMP_FLUSH() do { if (A.dbg && (threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) A.dbg[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + i_] = stamp_[i_]; } } while (0)
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(OB_DEC2_THREADS) void ob_dec_gemv2_kernel(const ObG
                             for (int v = 0; v < 4; ++v) av[v] = (int)(ww & (0x01010101u << (4 * jh + v)));
                             acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[p], acc[j], 0, 0, 0);
                         }
-#ifdef OB_PROFILE_ABLATE
+#ifdef OB_PROFILE_STAMPS
                         if (g == 0 && q == 0 && jh == 0) OB_STAMP(7);
 #endif
                     }

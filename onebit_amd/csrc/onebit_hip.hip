@@ -505,7 +505,7 @@ static int ob_ablate_mode()
     return mode;
 }
 
-#ifdef OB_PROFILE_ABLATE
+#ifdef OB_PROFILE_STAMPS
 static unsigned long long *g_dbg = nullptr;
 extern "C" int onebit_debug_read_timing(unsigned long long *host_out, int nblocks)
 {
@@ -519,7 +519,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 {
     ObGemvArgs a = a_in;
     a.ablate = ob_ablate_mode();
-#ifdef OB_PROFILE_ABLATE
+#ifdef OB_PROFILE_STAMPS
     if (getenv("OB_TIMING")) {
         if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 128 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 128 * sizeof(unsigned long long)); }
         a.dbg = g_dbg;
