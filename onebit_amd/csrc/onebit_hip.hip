@@ -13,6 +13,7 @@
 #include "ob_decode.h"
 #include "ob_decode2.h"
 #include "ob_gemm.h"
+#include "ob_gemm2.h"
 #include "ob_skinny.h"
 #include "ob_batch.h"
 
@@ -135,6 +136,7 @@ static void ob_launch_simple(const void *packed, int64_t ldw_bytes, const void *
                        (int)T, (int)K, (int)N);
 }
 
+static int ob_cu_count();
 static inline size_t ob_skinny_lds(int rt) { return OB_SKINNY_LDS(rt); }
 
 template <bool PARTIAL, int RT>
@@ -186,7 +188,20 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
         else if (T <= 16) OB_GEMM_GO(4, 1, 1, 1);
         else if (T <= 32) OB_GEMM_GO(4, 1, 1, 2);
         else if (T <= 64) OB_GEMM_GO(4, 1, 1, 4);
-        else OB_GEMM_GO(2, 2, 4, 4);
+        else {
+            // large T with K % 64 == 0: the 256 x 256 / 8-wave kernel (ob_gemm2.h); OB_GEMM2=0 keeps the 128 x 128 one, =2 forces it
+            static const int gemm2_env = getenv("OB_GEMM2") ? atoi(getenv("OB_GEMM2")) : 1;
+            // (worth it from ~4 rounds of 256 x 256 tiles over the CUs; smaller problems quantise badly)
+            const int64_t tiles2 = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + OB_G2_T - 1) / OB_G2_T);
+            if (gemm2_env && (tiles2 >= 4 * (int64_t)ob_cu_count() || gemm2_env == 2) && T >= 192 && K % OB_G2_K == 0 && N % 4 == 0 && ldx % 8 == 0) {
+                static bool attr_set[OB_MAX_DEVICES] = {};
+                ob_set_max_lds_once(ob_gemm2_f16_kernel<PARTIAL>, attr_set, OB_G2_LDS);
+                const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
+                hipLaunchKernelGGL((ob_gemm2_f16_kernel<PARTIAL>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G2_LDS, s,
+                                   (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)x, ldx, (const _Float16 *)h,
+                                   (const _Float16 *)g, (_Float16 *)u, zp, (int)T, (int)K, (int)N, nbn);
+            } else OB_GEMM_GO(2, 2, 4, 4);
+        }
 #undef OB_SKINNY_GO
 #undef OB_GEMM_GO
         return;

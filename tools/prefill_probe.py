@@ -3,7 +3,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from onebit_amd import BitLinearInf, _lib
 from onebit_amd.bitnet import _stream_ptr
-if os.environ.get("OB_EXTRA"):
+if os.environ.get("OB_LIB"):
+    _lib.LIB_PATH = os.environ["OB_LIB"]
+elif os.environ.get("OB_EXTRA"):
     import subprocess
     so = "/tmp/libonebit_exp.so"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
@@ -11,7 +13,7 @@ if os.environ.get("OB_EXTRA"):
     _lib.LIB_PATH = so
 dev = torch.device("cuda:0")
 lib = _lib.load()
-SHAPES = [(16384, 4096, 11008)] if os.environ.get("OB_EXTRA") else None
+SHAPES = [(16384, 4096, 11008)] if (os.environ.get("OB_EXTRA") or os.environ.get("OB_ONE")) else None
 for (T, K, N) in SHAPES or [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 4096, 4096), (2048, 4096, 11008), (256, 4096, 11008), (64, 4096, 11008), (32, 4096, 11008), (16, 4096, 11008), (8, 4096, 11008), (2, 4096, 11008), (32, 11008, 4096), (32, 4096, 4096), (16, 4096, 4096)]:
     m = BitLinearInf(K, N, dtype=torch.float16).to(dev)
     m.weight.data = torch.randint(0, 256, (N, K // 8), dtype=torch.uint8, device=dev).view(torch.int8)
