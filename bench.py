@@ -353,6 +353,32 @@ def measure_prefill_model(model, dev, B=8, S=2048):
             "attention": "sdpa", "glue": "onebit_rows_res_ln_rms + onebit_rows_swiglu", "per": "GPU"}
 
 
+def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048):
+    """BASELINE configs[2] under model-level tensor parallelism (onebit_amd/tp.py): q|k|v by head ->
+    local attention -> o K-sharded, gate|up N-sharded -> down K-sharded; two activation exchanges
+    (reduce_scatter fp32 + all_gather fp16 of [T, hidden]) per layer over RCCL.  Every rank holds the
+    same checkpoint here (seeded identically by the caller) and keeps 1/world of the 1-bit weights."""
+    from onebit_amd.tp import TensorParallelPrefill
+    cfg = model.config
+    S = min(S, cfg.max_position_embeddings)
+    ids = torch.randint(0, cfg.vocab_size, (B, S), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev)
+    tp = TensorParallelPrefill(model, rank, world, attention="sdpa")
+    try:
+        tp(ids[:1, :128], gather_logits=False)
+        dt, dmin = _timed(lambda: tp(ids, gather_logits=False), dev, world, warm=2, iters=20)
+    finally:
+        del tp
+        torch.cuda.empty_cache()
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    w1 = L * (4 * H * H + 3 * H * I)
+    T = B * S
+    return {"batch": B, "seq_len": S, "tp_degree": world, "ms": round(dt * 1e3, 1), "ms_min": round(dmin * 1e3, 1), "iterations": 20,
+            "tokens_per_s": round(T / dt, 1), "onebit_layer_TFLOPs_equivalent": round(2.0 * T * w1 / dt / 1e12, 1),
+            "exchanges_per_layer": 2 if world > 1 else 0,
+            "bytes_per_exchange_per_rank": (T * H * 4 + T * H * 2) if world > 1 else 0,
+            "attention": "sdpa on the local heads", "logits": "own token rows only (not gathered)"}
+
+
 def measure_cpu_baseline(cfg):
     """The oracle's reference-style CPU path (dense +-1 matrix rebuilt on every call, then a dense
     fp32 GEMV, *g, LayerNorm -- bitnet.py:98-118 restated in C), single thread, on the 7 projections
@@ -514,6 +540,16 @@ def main():
             pmodel = measure_prefill_model(model, dev)
         except Exception as e:
             pmodel = {"error": "%s: %s" % (type(e).__name__, e)}
+    pmodel_tp = None
+    if not args.no_prefill:
+        try:
+            if world > 1:                       # the same checkpoint on every rank (the decode replicas were seeded per rank)
+                del model
+                torch.cuda.empty_cache()
+                model = build_synthetic_model(cfg, seed=4242, device=dev)
+            pmodel_tp = measure_prefill_model_tp(model, dev, world, rank)
+        except Exception as e:
+            pmodel_tp = {"error": "%s: %s" % (type(e).__name__, e)}
     ksd = None
     if args.k_sharded_decode or world > 1:      # BASELINE config 4 whenever there is more than one rank: LLaMA-13B shapes
         try:
@@ -560,6 +596,8 @@ def main():
             out["continuous_batch"] = serve
         if pmodel is not None:
             out["prefill_model"] = pmodel
+        if pmodel_tp is not None:
+            out["prefill_model_tp"] = pmodel_tp
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -123,3 +123,25 @@ def test_fused_glue_forward_within_fp16_tolerance(golden_dir, name):
     lg2 = model(torch.tensor([[int(toks[0]), int(toks[1])]], device=dev), cache).cpu().numpy()   # 2 tokens on top of the cache
     assert np.abs(lg2[0, 0] - z["decode_logits_f16"][0][0]).max() <= tol
     assert np.abs(lg2[0, 1] - z["decode_logits_f16"][0][1]).max() <= tol
+
+
+def test_tensor_parallel_prefill_world1_matches_module_path():
+    """onebit_amd/tp.py with the HIP callbacks at tensor-parallel degree 1 (the only degree a 1-GPU box
+    offers; degree 2 runs on CPU over gloo in tests/test_tp_cpu.py): K-sharded o / down through
+    onebit_matmul_partial + onebit_scale_layernorm, N-sharded q|k|v / gate|up through the row-statistics
+    kernels, against the module path's logits."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.tp import TensorParallelPrefill
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1408, num_hidden_layers=3,
+                            num_attention_heads=8, num_key_value_heads=4, max_position_embeddings=128)
+    model = build_synthetic_model(cfg, seed=6, device=dev)
+    ids = torch.randint(0, 512, (3, 37), generator=torch.Generator().manual_seed(2)).to(dev)
+    ref = model(ids)
+    tp = TensorParallelPrefill(model, 0, 1)
+    got = tp(ids)
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 6e-3 * scale
+    assert tp.exchanges == 2 * cfg.num_hidden_layers
+    assert tp.kv[0][0].shape == (3, 4, 37, cfg.head_dim)
