@@ -129,7 +129,20 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm2_f16_kernel(
             for (int rn = 0; rn < RN; ++rn) asm volatile("global_load_dword %0, %1, off" : "=v"(w2[rn]) : "v"(wrow[rn] + 2 * (ks + 2)) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        // all sign expansions of the step first (one VALU burst), then two dense bursts of 32 MFMAs: an
+        // MFMA that waits for an expansion issued just before it stalls the wave's whole in-order stream
         uint32_t e[RN][8];
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) {
+#if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 1)
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) e[rn][i] = w0[rn] + i;                           // ablation: no sign expansion
+#else
+            ob_expand16((w0[rn] >> wsh) & 0xffffu, e[rn]);
+#endif
+        }
+#ifdef OB_G2_BURST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             ob_half8 bop[RT];
@@ -140,19 +153,23 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm2_f16_kernel(
 #else
                 bop[rt] = *reinterpret_cast<const ob_half8 *>(&As[cur][wt * 128 + rt * 16 + r][ob_g2_swz(r, gq * 2 + s) * 8]);
 #endif
+#ifdef OB_G2_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int rn = 0; rn < RN; ++rn) {
-#if defined(OB_GEMM_ABL) && (OB_GEMM_ABL & 1)
-                if (s == 0) { _Pragma("unroll") for (int i = 0; i < 8; ++i) e[rn][i] = w0[rn] + i; }       // ablation: no sign expansion
-#else
-                if (s == 0) ob_expand16((w0[rn] >> wsh) & 0xffffu, e[rn]);
-#endif
                 const ob_u32x4 av = {e[rn][4 * s + 0], e[rn][4 * s + 1], e[rn][4 * s + 2], e[rn][4 * s + 3]};
                 const ob_half8 aop = __builtin_bit_cast(ob_half8, av);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rn][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, bop[rt], acc[rn][rt], 0, 0, 0);
             }
+#ifdef OB_G2_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef OB_G2_BURST
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more2) {
