@@ -947,9 +947,15 @@ __device__ __forceinline__ float ob_rows_max(float v)
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-template <bool PST>
-__global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAttnArgs A_in)
+// NTH = 512 or 256 threads.  The kernel is a chain of dependent phases on 32 workgroups; a wave that
+// has its SIMD to itself issues an instruction every ~4.7 cycles against ~9 when two waves share it
+// (tools/issue_probe.hip), and most of a wave's instructions here do not scale with its share of the
+// positions -- so the single-sequence decode step runs it with 4 waves (one per SIMD), 8 positions
+// per thread and sweep; the batched step (many workgroups per CU anyway) keeps 8 waves.
+template <bool PST, int NTH>
+__global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 {
+    constexpr int NWV = NTH / 64, PG = NTH / 16, NI = 128 / PG;
     ObAttnArgs A = A_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
@@ -967,7 +973,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     _Float16 *k_s = q_s + 128;                                       // [128] new key (post RoPE)
     _Float16 *v_s = k_s + 128;                                       // [128] new value
     float *po = reinterpret_cast<float *>(v_s + 128);                // [8 waves][128] partial outputs
-    float *sc = po + OB_ATTN_WAVES * 128;                            // [max_len] scores of positions >= 128
+    float *sc = po + NWV * 128;                            // [max_len] scores of positions >= 128
 
     // ---- every load of the short-context path is issued here ------------------------------------
     // The first 128 cached positions are fetched WITHOUT waiting for the position (one dependent
@@ -979,10 +985,10 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     const int ds = tid & 15, pg = tid >> 4;
     const bool dok = 8 * ds < D;
     const int dcl = dok ? 8 * ds : 0;
-    ob_half8 kreg[4], vreg[4];
+    ob_half8 kreg[NI], vreg[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t off = (int64_t)min(pg + 32 * i, A.max_len - 1) * D + dcl;
+    for (int i = 0; i < NI; ++i) {
+        const int64_t off = (int64_t)min(pg + PG * i, A.max_len - 1) * D + dcl;
         kreg[i] = *reinterpret_cast<const ob_half8 *>(kbase + off);
         vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
     }
@@ -1010,16 +1016,16 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     } else {
         const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        for (int base = tid * 8; base < NQ; base += OB_ATTN_THREADS * 8)
+        for (int base = tid * 8; base < NQ; base += NTH * 8)
             ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
-        for (int base = tid * 8; base < NK; base += OB_ATTN_THREADS * 8) {
+        for (int base = tid * 8; base < NK; base += NTH * 8) {
             ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
             ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
         }
         float s[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] = a2[i][0] + a2[i][1];
-        ob_block_sum_n<6, OB_ATTN_WAVES>(s, red);                        // barrier 1
+        ob_block_sum_n<6, NWV>(s, red);                        // barrier 1
         ob_ln_stats(s[0], s[1], cq, NQ, A.ln_eps, mq, rq);
         ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
         ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
@@ -1059,11 +1065,11 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     const ob_half8 q8 = *reinterpret_cast<const ob_half8 *>(q_s + 8 * ds);       // zero beyond D
     const ob_half8 kn8 = *reinterpret_cast<const ob_half8 *>(k_s + 8 * ds);
     const ob_half8 vn8 = *reinterpret_cast<const ob_half8 *>(v_s + 8 * ds);
-    float sreg[4];
+    float sreg[NI];
     float lmax = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = pg + 32 * i;
+    for (int i = 0; i < NI; ++i) {
+        const int p = pg + PG * i;
         const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
         const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
         sreg[i] = p < L ? sv : -INFINITY;
@@ -1071,8 +1077,8 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     }
     for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p0 + pg + 32 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int p = p0 + pg + PG * i;
             if (p < L) {
                 const ob_half8 k8 = p == pos ? kn8 : *reinterpret_cast<const ob_half8 *>(kbase + (int64_t)p * D + dcl);
                 const float dot = ob_row_sum(dot8(q8, k8));
@@ -1088,16 +1094,20 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     __syncthreads();                                                 // barrier 3
     float gmax;
     {
-        const ob_float4 m0 = *reinterpret_cast<const ob_float4 *>(red + 96), m1 = *reinterpret_cast<const ob_float4 *>(red + 100);
-        gmax = fmaxf(fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
+        const ob_float4 m0 = *reinterpret_cast<const ob_float4 *>(red + 96);
+        gmax = fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3]));
+        if (NWV == 8) {
+            const ob_float4 m1 = *reinterpret_cast<const ob_float4 *>(red + 100);
+            gmax = fmaxf(gmax, fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3])));
+        }
     }
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
+    for (int i = 0; i < NI; ++i) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
     for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p0 + pg + 32 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int p = p0 + pg + PG * i;
             if (p < L) {                       // sc[p] was written by lane ds == 0 of this same row
                 const float e = __expf(sc[p] - gmax);
                 if (ds == 0) sc[p] = e;
@@ -1110,14 +1120,19 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     __syncthreads();                                                 // barrier 4
     float inv_l;
     {
-        const ob_float4 l0 = *reinterpret_cast<const ob_float4 *>(red + 112), l1 = *reinterpret_cast<const ob_float4 *>(red + 116);
-        inv_l = 1.0f / (((l0[0] + l0[1]) + (l0[2] + l0[3])) + ((l1[0] + l1[1]) + (l1[2] + l1[3])));
+        const ob_float4 l0 = *reinterpret_cast<const ob_float4 *>(red + 112);
+        float lt = (l0[0] + l0[1]) + (l0[2] + l0[3]);
+        if (NWV == 8) {
+            const ob_float4 l1 = *reinterpret_cast<const ob_float4 *>(red + 116);
+            lt += (l1[0] + l1[1]) + (l1[2] + l1[3]);
+        }
+        inv_l = 1.0f / lt;
     }
     // out = P . V over this thread's positions and 8 dims
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = pg + 32 * i;
+    for (int i = 0; i < NI; ++i) {
+        const int p = pg + PG * i;
         const float pr = ob_round_h(sreg[i] * inv_l);
         const ob_half8 vv = p == pos ? vn8 : vreg[i];
         if (p < L) {
@@ -1127,8 +1142,8 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     }
     for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p0 + pg + 32 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int p = p0 + pg + PG * i;
             if (p < L) {
                 const float pr = ob_round_h(sc[p] * inv_l);
                 const ob_half8 vv = p == pos ? vn8 : *reinterpret_cast<const ob_half8 *>(vbase + (int64_t)p * D + dcl);
@@ -1148,7 +1163,7 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_kernel(const ObAt
     if (tid < D) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < OB_ATTN_WAVES; ++w) acc += po[w * 128 + tid];
+        for (int w = 0; w < NWV; ++w) acc += po[w * 128 + tid];
         A.out[head * D + tid] = (_Float16)acc;
     }
 }

@@ -764,7 +764,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         at.ln_eps = m->ln_eps; at.slot_stride = (long long)m->n_kv_heads * m->max_len * D;
         const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
-        hipLaunchKernelGGL(ob_dec_attn_kernel<false>, dim3(m->n_heads, B), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+        hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
         if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
@@ -915,8 +915,11 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         } else {
             const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
             if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
-            if (at.st_q) hipLaunchKernelGGL(ob_dec_attn_kernel<true>, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
-            else hipLaunchKernelGGL(ob_dec_attn_kernel<false>, dim3(m->n_heads), dim3(OB_ATTN_THREADS), attn_lds, s, at);
+            // one wave per SIMD (256 threads) for the single sequence; OB_ATTN_THREADS=512 restores 8 waves (A/B)
+            static const int attn_threads = getenv("OB_ATTN_THREADS") ? atoi(getenv("OB_ATTN_THREADS")) : 256;
+            if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(m->n_heads), dim3(256), attn_lds, s, at);
+            else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512>), dim3(m->n_heads), dim3(512), attn_lds, s, at);
+            else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(m->n_heads), dim3(512), attn_lds, s, at);
             if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
         }
         // K3: o_proj
