@@ -195,8 +195,8 @@ int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t 
  * projection is ONE skinny-GEMM launch over the [B, K] activations of all sequences (packed
  * weights streamed once per step), the row-wise glue (residual + LayerNorm + RMSNorm, SiLU * up)
  * runs once per row, attention once per (head, sequence) on that sequence's KV-cache slot.
- * 8 launches per decoder layer (q|k|v and gate|up share one launch each) + the final norm; lm_head / sampling are the caller's (x_out is the
- * final-norm output [B, hidden], ready for a dense fp16 GEMM).
+ * 8 launches per decoder layer (q|k|v and gate|up share one launch each) + the final norm (x_out is the
+ * final-norm output [B, hidden]) + optionally the batched lm_head and the per-sequence argmax.
  * layer->k_cache / v_cache here are [B][n_kv_heads][max_len][head_dim]; pos[b] < 0 marks an idle
  * slot (its row is computed but attention and the cache append are skipped).  2 <= B <= 64.
  */
@@ -211,6 +211,14 @@ typedef struct onebit_batch_state {
     void *attn_out, *u_o;       /* fp16 [B, hidden]                                             */
     void *u_gate, *u_up;        /* fp16 [B, intermediate]                                       */
     void *u_down;               /* fp16 [B, hidden]                                             */
+    /* optional: lm_head + greedy sampling inside the step (modeling_bitllama.py:1610-1611,
+     * generation/utils.py:2540).  With next_tokens != NULL (and model->lm_head set, hidden % 64 == 0)
+     * the fp16 lm_head matrix is streamed once for all B rows and next_tokens[b] = argmax of row
+     * b's logits (first index on ties); logits, if given, receives the fp16 logits.              */
+    int32_t *next_tokens;       /* device [B] out, or NULL: the caller does lm_head / sampling  */
+    void *logits;               /* fp16 [B, vocab] or NULL                                      */
+    float *part_val;            /* fp32 [ceil(vocab / 128) * 64] scratch (with next_tokens)     */
+    int32_t *part_idx;          /* int32 [ceil(vocab / 128) * 64] scratch (with next_tokens)    */
 } onebit_batch_state_t;
 
 int onebit_decode_step_batched(const onebit_model_t *model, const onebit_batch_state_t *state, void *stream);

@@ -150,3 +150,168 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batched lm_head + greedy sampling (modeling_bitllama.py:1610-1611, generation/utils.py:2540):
+// logits[b][v] = fp16( sum_k x[b][k] * W[v][k] ), next[b] = argmax_v (first index on ties).
+// The fp16 lm_head matrix (2 V H bytes: 262 MB at 7B) is streamed ONCE per step for all B <= 64
+// sequences: a workgroup owns 128 vocabulary rows (8 waves x 16 rows); K advances in chunks of 256
+// whose activations [B, 256] all threads stage into LDS (32 KB, double buffered, one barrier per
+// chunk) while each lane streams its row's 512 bytes of the chunk straight into MFMA A operands
+// (v_mfma_f32_16x16x32_f16, weights = A, tokens = B operand, as everywhere).  HBM-bound: the MFMA work
+// is 2 instructions per KB of weights.  Per-workgroup (max, index) per sequence go to scratch; a
+// second tiny kernel reduces them over the workgroups.
+// ---------------------------------------------------------------------------------------------
+struct ObBHeadArgs {
+    const _Float16 *x;            // [B, H] final-norm output
+    const _Float16 *lm_w;         // [V, H]
+    _Float16 *logits;             // [B, V] or NULL
+    float *part_val;              // [grid][64]
+    int *part_idx;                // [grid][64]
+    int B, H, V;
+};
+#define OB_BH_ROWS 128
+#define OB_BH_K 256
+#define OB_BH_PITCH (OB_BH_K + 8)            // halves per LDS row (528 B)
+
+template <int TT>                            // token tiles of 16: B <= 16 * TT
+__global__ __launch_bounds__(512) void ob_b_lmhead_kernel(const ObBHeadArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 (*xs)[TT * 16][OB_BH_PITCH] = reinterpret_cast<_Float16 (*)[TT * 16][OB_BH_PITCH]>(smem);
+    float *rv = reinterpret_cast<float *>(smem + (size_t)2 * TT * 16 * OB_BH_PITCH * 2);      // [8 waves][TT*16]
+    int *ri = reinterpret_cast<int *>(rv + 8 * TT * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, gq = lane >> 4;
+    const int H = A.H, B = A.B, V = A.V;
+    const int v0 = blockIdx.x * OB_BH_ROWS + wave * 16;
+    const _Float16 *wrow = A.lm_w + (int64_t)min(v0 + r, V - 1) * H + gq * 16;       // lane: 16 consecutive k per 64-k block
+    const int nkc = (H + OB_BH_K - 1) / OB_BH_K;
+
+    // staging: thread -> (token st_b + 16 i, halves st_k .. st_k + 7) of a [TT*16, 256] chunk
+    const int st_b = tid >> 5, st_k = (tid & 31) * 8;
+    auto stage = [&](int kc, int buf) {
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const int b = st_b + 16 * i, k = kc * OB_BH_K + st_k;
+            ob_half8 v = (ob_half8)(_Float16)0;
+            if (b < B && k < H) v = *reinterpret_cast<const ob_half8 *>(A.x + (int64_t)b * H + k);
+            *reinterpret_cast<ob_half8 *>(&xs[buf][b][st_k]) = v;
+        }
+    };
+    ob_float4 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int buf = kc & 1;
+        // this lane's 8 x 16 bytes of its row for the chunk (non-temporal: read exactly once per step)
+        ob_half8 wf[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kc * OB_BH_K + q * 64;
+            const int kk = min(k, H - 64);                       // H % 64 == 0 (host-checked); clamp the tail chunk
+            wf[2 * q] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(wrow + kk));
+            wf[2 * q + 1] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(wrow + kk + 8));
+        }
+        if (kc + 1 < nkc) stage(kc + 1, buf ^ 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (kc * OB_BH_K + q * 64 < H) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const ob_half8 bx = *reinterpret_cast<const ob_half8 *>(&xs[buf][t * 16 + r][q * 64 + gq * 16 + 8 * s]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[2 * q + s], bx, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D[v][b]: lane holds v = v0 + 4 gq + i (i = 0..3), b = t * 16 + r
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int b = t * 16 + r;
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = v0 + 4 * gq + i;
+            const float lg = ob_round_h(acc[t][i]);                // logits are fp16 tensors in the reference
+            if (v < V && (lg > best || (lg == best && v < besti))) { best = lg; besti = v; }
+        }
+        if (A.logits && b < B) {
+            const int vb = v0 + 4 * gq;
+            if (vb + 3 < V && (V & 3) == 0) {
+                const ob_half4 o = {(_Float16)acc[t][0], (_Float16)acc[t][1], (_Float16)acc[t][2], (_Float16)acc[t][3]};
+                *reinterpret_cast<ob_half4 *>(A.logits + (int64_t)b * V + vb) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (vb + i < V) A.logits[(int64_t)b * V + vb + i] = (_Float16)acc[t][i];
+            }
+        }
+        // over the 4 lane groups (rows of 16 lanes) of the wave: the two gfx950 row swaps
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            uint32_t ov, oi;
+            if (step == 0) {
+                auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                auto c = __builtin_amdgcn_permlane16_swap((uint32_t)besti, (uint32_t)besti, false, false);
+                // with both operands equal the swap returns {own value, partner row's value} in some order:
+                // the XOR of the pair with our own value is the partner's
+                ov = a[0] ^ a[1] ^ __float_as_uint(best); oi = c[0] ^ c[1] ^ (uint32_t)besti;
+            } else {
+                auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                auto c = __builtin_amdgcn_permlane32_swap((uint32_t)besti, (uint32_t)besti, false, false);
+                ov = a[0] ^ a[1] ^ __float_as_uint(best); oi = c[0] ^ c[1] ^ (uint32_t)besti;
+            }
+            const float pv = __uint_as_float(ov);
+            const int pi = (int)oi;
+            if (pv > best || (pv == best && pi < besti)) { best = pv; besti = pi; }
+        }
+        if (gq == 0) { rv[wave * TT * 16 + b] = best; ri[wave * TT * 16 + b] = besti; }
+    }
+    __syncthreads();
+    if (tid < TT * 16) {
+        float bv = rv[tid];
+        int bi = ri[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float v = rv[w * TT * 16 + tid];
+            const int i = ri[w * TT * 16 + tid];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+        A.part_val[blockIdx.x * 64 + tid] = bv;
+        A.part_idx[blockIdx.x * 64 + tid] = bi;
+    }
+}
+
+// next[b] = argmax over the workgroup partials (first index on ties); one workgroup per sequence
+__global__ __launch_bounds__(256) void ob_b_argmax_kernel(const float *part_val, const int *part_idx, int nparts, int vocab,
+                                                          int *next_tokens)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const float v = part_val[i * 64 + b];
+        const int ix = part_idx[i * 64 + b];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float v = sv[threadIdx.x + off];
+            const int ix = si[threadIdx.x + off];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) next_tokens[b] = (si[0] >= 0 && si[0] < vocab) ? si[0] : 0;      // all-NaN logits: clamp
+}

@@ -807,7 +807,30 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     else nf.u_prev = (const _Float16 *)st->u_down;
     nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
     hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nf);
-    return ob_launch_status("decode_step_batched(final norm)");
+    if ((rc = ob_launch_status("decode_step_batched(final norm)"))) return rc;
+    if (!st->next_tokens) return 0;
+    // batched lm_head + greedy sampling
+    if (!m->lm_head || m->vocab <= 0 || !st->part_val || !st->part_idx)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: next_tokens needs model->lm_head, vocab and the part_val / part_idx scratch");
+    if (H % 64 != 0) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: lm_head needs hidden %% 64 == 0");
+    ObBHeadArgs ha = {(const _Float16 *)st->x, (const _Float16 *)m->lm_head, (_Float16 *)st->logits, st->part_val, st->part_idx,
+                      B, H, m->vocab};
+    const int hg = (m->vocab + OB_BH_ROWS - 1) / OB_BH_ROWS;
+#define OB_BH_GO(TT_)                                                                                              \
+    do {                                                                                                           \
+        const size_t lds = (size_t)2 * TT_ * 16 * OB_BH_PITCH * 2 + (size_t)8 * TT_ * 16 * 8;                      \
+        static bool attr_set[OB_MAX_DEVICES] = {};                                                                 \
+        ob_set_max_lds_once(ob_b_lmhead_kernel<TT_>, attr_set, (int)lds);                                          \
+        hipLaunchKernelGGL(ob_b_lmhead_kernel<TT_>, dim3(hg), dim3(512), lds, s, ha);                              \
+    } while (0)
+    if (B <= 16) OB_BH_GO(1);
+    else if (B <= 32) OB_BH_GO(2);
+    else OB_BH_GO(4);
+#undef OB_BH_GO
+    if ((rc = ob_launch_status("decode_step_batched(lm_head)"))) return rc;
+    hipLaunchKernelGGL(ob_b_argmax_kernel, dim3(B), dim3(256), 0, s, (const float *)st->part_val, (const int *)st->part_idx, hg,
+                       m->vocab, st->next_tokens);
+    return ob_launch_status("decode_step_batched(argmax)");
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,

@@ -53,7 +53,8 @@ class _State(ctypes.Structure):
 class _BatchState(ctypes.Structure):
     _fields_ = [("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
-                ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp)]
+                ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
+                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp)]
 
 
 class _FusedIn(ctypes.Structure):
@@ -300,7 +301,8 @@ class BatchedDecodeStep:
     (head, slot)); the caller owns scheduling, lm_head and sampling.  ``caches[l] = (k, v)`` with k, v
     ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
 
-    def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int):
+    def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
+                 keep_logits: bool = False):
         cfg = model.config
         p = model.lm_head.weight
         if not p.is_cuda:
@@ -328,16 +330,29 @@ class BatchedDecodeStep:
                         u_k=z(batch, Hkv), u_v=z(batch, Hkv), attn_out=z(batch, Hq), u_o=z(batch, H),
                         u_gate=z(batch, I), u_up=z(batch, I), u_down=z(batch, H))
         b = self.buf
+        # lm_head + greedy argmax inside the step (the fp16 lm_head streamed once for all rows); needs hidden % 64 == 0
+        self.next_tokens = self.logits = None
+        nt = lg = pv = pi = None
+        if sample and H % 64 == 0:
+            nparts = -(-cfg.vocab_size // 128) * 64
+            self.next_tokens = torch.zeros(batch, dtype=torch.int32, device=dev)
+            self._part_val = torch.zeros(nparts, dtype=torch.float32, device=dev)
+            self._part_idx = torch.zeros(nparts, dtype=torch.int32, device=dev)
+            nt, pv, pi = self.next_tokens.data_ptr(), self._part_val.data_ptr(), self._part_idx.data_ptr()
+            if keep_logits:
+                self.logits = torch.zeros(batch, cfg.vocab_size, dtype=f16, device=dev)
+                lg = self.logits.data_ptr()
         self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
-                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr())
+                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi)
         self.lib.onebit_decode_step_batched.restype = ctypes.c_int
         self.lib.onebit_decode_step_batched.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_BatchState), _vp]
 
     def launch(self) -> torch.Tensor:
         """Enqueue one step on the current stream; returns the final-norm output x [B, hidden]
-        (a view of a persistent buffer: multiply by lm_head^T for logits)."""
+        (a view of a persistent buffer).  With ``sample`` the greedy next token of every slot is in
+        ``self.next_tokens`` (int32 [B]) afterwards, computed by the same call."""
         with torch.cuda.device(self.dev):
             rc = self.lib.onebit_decode_step_batched(ctypes.byref(self._model), ctypes.byref(self._state),
                                                      torch.cuda.current_stream(self.dev).cuda_stream)

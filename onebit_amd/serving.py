@@ -157,7 +157,10 @@ class ContinuousBatcher:
             self._native.tokens.copy_(self._g_ids)
             self._native.pos.copy_(self._g_pos_native)
             x = self._native.launch()
-            self._g_next.copy_((x @ self.model.lm_head.weight.t()).float().argmax(-1))
+            if self._native.next_tokens is not None:              # lm_head + argmax ran inside the C step
+                self._g_next.copy_(self._native.next_tokens)
+            else:
+                self._g_next.copy_((x @ self.model.lm_head.weight.t()).float().argmax(-1))
             return
         cfg, m = self.cfg, self.model.model
         H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim

@@ -68,3 +68,33 @@ def test_native_batched_step_on_7b_shaped_layers():
             j = next(i for i in range(m) if got[i] != ref[i])
             lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
             assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
+
+
+@pytest.mark.parametrize("batch,vocab", [(5, 1000), (32, 32000), (48, 4099)])
+def test_batched_lm_head_and_argmax_inside_the_step(batch, vocab):
+    """onebit_decode_step_batched with next_tokens: the fp16 logits of every slot against the dense
+    product of the step's own final-norm output with lm_head (fp32 accumulate -> fp16, as
+    modeling_bitllama.py:1610 computes them), and the greedy token = argmax (first index on ties)."""
+    from onebit_amd.engine import BatchedDecodeStep
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=vocab, hidden_size=512, intermediate_size=1408, num_hidden_layers=1,
+                            num_attention_heads=8, max_position_embeddings=32)
+    model = build_synthetic_model(cfg, seed=21, device=dev)
+    shape = (batch, cfg.num_key_value_heads, 16, cfg.head_dim)
+    caches = [(torch.zeros(shape, device=dev, dtype=torch.float16), torch.zeros(shape, device=dev, dtype=torch.float16))]
+    step = BatchedDecodeStep(model, caches, batch, 16, sample=True, keep_logits=True)
+    g = torch.Generator().manual_seed(3)
+    step.tokens.copy_(torch.randint(0, vocab, (batch,), generator=g).to(torch.int32))
+    step.pos.zero_()
+    x = step.launch()
+    torch.cuda.synchronize()
+    ref = (x.float() @ model.lm_head.weight.float().t())
+    got = step.logits.float()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2.0 ** -9 * max(1.0, scale)          # fp16 rounding of the same sums
+    tok = step.next_tokens.long()
+    assert tok.min() >= 0 and tok.max() < vocab
+    # greedy token: argmax of the kernel's own fp16 logits, lowest index on ties
+    assert torch.equal(tok, got.argmax(-1)) or all(
+        float(got[b, tok[b]]) == float(got[b].max()) and int(tok[b]) == int((got[b] == got[b].max()).nonzero()[0]) for b in range(batch))
