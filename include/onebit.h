@@ -72,9 +72,11 @@ int onebit_unpack_signs(const void *packed, void *out, int dtype, int64_t N, int
  *   K % 32 == 0 with 4-byte aligned packed rows (every LLaMA shape; 16-byte
  *   aligned rows get the widest loads); other shapes run a generic kernel.
  *   x, y rows contiguous; x/h/y 16-byte aligned.  u_or_null, if given,
- *   receives the pre-LayerNorm u [T,N].  workspace:
- *   onebit_linear_workspace_bytes() bytes (0 for MFMA shapes), 16-byte
- *   aligned, caller-owned scratch.
+ *   receives the pre-LayerNorm u [T,N].  workspace: caller-owned, 16-byte
+ *   aligned scratch of onebit_linear_workspace_bytes() bytes: required only
+ *   for K % 32 != 0 (fp32 z); for large prefill calls it holds the pre-scaled
+ *   activations fp16(x*h) of the LDS-DMA GEMM -- without it (NULL / smaller)
+ *   the register-staged GEMM runs instead, same results.
  */
 size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype);
 int onebit_linear_forward(const void *packed, int64_t ldw_bytes, const void *x, const void *h,

@@ -222,5 +222,247 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm2_f16_kernel(
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA form: the same tiling on PRE-SCALED activations a[t][k] = fp16(x[t][k] * h[k]) (one
+// elementwise pass per call, ob_scale_rows_kernel: 2 * T * K * 2 bytes of traffic, ~3 % of the GEMM at
+// T = 16384).  With the rounding of bitnet.py:113 done up front a tile needs no arithmetic on its
+// way in, so it goes global -> LDS by global_load_lds_dwordx4 (16 bytes per lane, 1 KB per wave
+// instruction, no VGPRs, no v_pk_mul, no ds_write): staging shrinks from 9 loads + 16 multiplies +
+// 4 LDS stores + a counted wait per thread and step to 4 DMA instructions per wave, which is what the
+// ablations of the register-staged kernel said it costs (957 -> 1372 TFLOP/s without staging).
+// The DMA writes wave-uniform base + 16 * lane: lane l of DMA i of wave w fills row (4w + i) * 8 +
+// (l >> 3), position l & 7, and FETCHES chunk (l & 7) ^ f(row) -- the XOR swizzle lives in the source
+// address.  Three LDS buffers, one __syncthreads per step (hipcc drains vmcnt before it: the tile
+// of step ks + 2 has the whole MFMA block of step ks to land).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ob_scale_rows_kernel(const _Float16 *__restrict__ x, int64_t ldx, const _Float16 *__restrict__ h,
+                                                            _Float16 *__restrict__ a, int64_t T, int K)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;      // 8 halves per thread; K % 8 == 0
+    if (i >= T * K) return;
+    const int64_t t = i / K;
+    const int k = (int)(i - t * K);
+    const ob_half8 xv = *reinterpret_cast<const ob_half8 *>(x + t * ldx + k);
+    const ob_half8 hv = *reinterpret_cast<const ob_half8 *>(h + k);
+    *reinterpret_cast<ob_half8 *>(a + i) = xv * hv;                       // fp16(x * h), bitnet.py:113
+}
+
+#define OB_G3_BUFS 4
+#define OB_G3_LDS (OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2 + 2 * 8192)      // 4 activation tiles + 2 weight quads
+template <bool PARTIAL>
+__global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
+    const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ a, int64_t lda,
+    const _Float16 *__restrict__ g, _Float16 *__restrict__ u, float *__restrict__ zp, int T, int K, int N, int nbn)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 (*As)[OB_G2_T][OB_G2_PITCH] = reinterpret_cast<_Float16 (*)[OB_G2_T][OB_G2_PITCH]>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 3, wt = wave >> 2;
+    const int r = lane & 15, gq = lane >> 4;
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
+    const int bid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
+    const int tt = bid / nbn, tn = bid - tt * nbn;
+    const int n0 = tn * OB_G2_N, t0 = tt * OB_G2_T;
+    const int nk = K / OB_G2_K;                 // K % 256 == 0 here (host-checked): whole quads of steps
+
+    // DMA source of this lane for each of the wave's 4 instructions per tile, as a 32-bit BYTE offset from
+    // the (scalar) base pointer: global_load_lds v_off, s[base:base+1] -- half the address registers of
+    // 64-bit per-lane pointers (the host checks T * lda * 2 < 4 GB)
+    uint32_t src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        // k order of a step: chunk c (= 2 * k-group + sub-step) of step 2m + par covers
+        // k = 128 m + 64 (c >> 2) + 32 par + 8 (c & 3) .. + 7 -- so that a lane's packed words of the two steps
+        // of a pair are ADJACENT (words 4m + 2 (gq >> 1) + par): one 8-byte load per row tile and pair
+        const int c = ob_g2_swz(row, lane & 7);
+        src[i] = (uint32_t)(((int64_t)min(t0 + row, T - 1) * lda + (c >> 2) * 64 + (c & 3) * 8) * 2);
+    }
+    const char *abase = reinterpret_cast<const char *>(a);
+    // The DMA is issued from inline asm: hipcc models the builtin as a FLAT access to both memory and LDS and,
+    // while one is pending, degrades every wait it inserts itself -- lgkmcnt for the operand reads included --
+    // to 0, which serialises the software-pipelined reads below with the MFMAs.  (M0 = LDS byte address of
+    // the wave's 1 KB destination; dynamic LDS starts at this kernel's LDS offset of smem.)
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    auto dma16 = [&](const char *base, uint32_t voff, uint32_t lds_addr) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
+    };
+    auto dma = [&](int tile) {
+        const uint32_t buf = (uint32_t)tile & (OB_G3_BUFS - 1);
+        const uint32_t kofs = (uint32_t)((tile >> 1) * 128 + (tile & 1) * 32) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dma16(abase, src[i] + kofs, lds0 + (buf * OB_G2_T + (wave_u * 4 + i) * 8) * (OB_G2_PITCH * 2));
+    };
+    // Weights go through LDS as well: while LDS-DMA transfers are pending hipcc turns EVERY wait for an
+    // ordinary global load into vmcnt(0) (and an asm load's destination registers are fair game for its
+    // register allocator while the data is still in flight -- it reused them as DMA addresses), so the loop
+    // has no register-destination global load at all.  One DMA instruction per wave and QUAD of steps
+    // (256 k = 32 bytes of a packed row): lane l of wave w fetches row 32 w + (l & 31), 16-byte half l >> 5
+    // (= pair of steps 2 q + (l >> 5)), landing at w * 1024 + (l >> 5) * 512 + (l & 31) * 16 of the quad's
+    // 8 KB buffer (two buffers).  A lane's 16 sign bits of a step sit in word 2 (gq >> 1) + par of the pair's
+    // 16 bytes (k order above): one ds_read_b64 per row tile and PAIR of steps, conflict-free (16 rows x 16 B,
+    // the two halves of a lane group pair broadcast).
+    const char *wbase = reinterpret_cast<const char *>(W);
+    const uint32_t wsrc = (uint32_t)((int64_t)min(n0 + 32 * wave + (lane & 31), N - 1) * ldw_words * 4 + 16 * (lane >> 5));
+    char *wlds = smem + OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2;
+    auto wdma = [&](int quad) {
+        dma16(wbase, wsrc + 32u * (uint32_t)quad, lds0 + OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2 + ((uint32_t)quad & 1) * 8192 + wave_u * 1024);
+    };
+    // row wn * 64 + rn * 16 + r: block (row >> 5) = 2 wn + (rn >> 1), row-in-block (rn & 1) * 16 + r
+    const char *wrd = wlds + wn * 2048 + r * 16 + 8 * (gq >> 1);
+    const int wsh = (gq & 1) * 16;
+
+    ob_float4 acc[RN][RT];
+#pragma unroll
+    for (int x_ = 0; x_ < RN; ++x_)
+#pragma unroll
+        for (int y_ = 0; y_ < RT; ++y_) acc[x_][y_] = (ob_float4){0.f, 0.f, 0.f, 0.f};
+    // the weight quad and all four tile buffers in flight before the first MFMA
+    wdma(0);
+    dma(0);
+    dma(1);
+    dma(2);
+    dma(3);                                     // nk % 4 == 0, nk >= 4 (host-checked)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (drains everything once)
+    ob_u32x2 wc[RN], wnx[RN];                   // packed words of the current / next pair of steps
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+        wc[rn] = *reinterpret_cast<const ob_u32x2 *>(wrd + (rn >> 1) * 1024 + (rn & 1) * 256);
+        wnx[rn] = wc[rn];
+    }
+    // operand reads are software-pipelined one half-step ahead of the MFMAs that consume them (two register
+    // sets): after a barrier all 8 waves would otherwise ask the LDS for 8 KB each at once and the matrix
+    // pipe idles until the first answers arrive -- 40 % of the kernel without any staging, by ablation
+    ob_half8 bopA[RT], bopB[RT];
+#ifndef OB_G3_ABL
+#define OB_G3_ABL 0                             // timing experiments only (tools/prefill_probe.py): 1 no operand reads,
+#endif                                          // 2 no sign expansion, 4 no DMA, 8 no wait / barrier -- results are wrong
+#define OB_G3_READ(DST, BUF, S)                                                                                          \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                    \
+        if (!(OB_G3_ABL & 1) || ks < 0)                                                                                  \
+            DST[rt] = *reinterpret_cast<const ob_half8 *>(&As[BUF][wt * 128 + rt * 16 + r][ob_g2_swz(r, gq * 2 + (S)) * 8]);
+    // sign expansion (ob_expand16's arithmetic) done PER operand, right before its 8 MFMAs: 4 live registers
+    // instead of 32 for the whole step
+#define OB_G3_MMA(SRC, S)                                                                                                \
+    _Pragma("unroll") for (int rn = 0; rn < RN; ++rn) {                                                                  \
+        ob_u32x4 av;                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                    \
+            av[p] = (OB_G3_ABL & 2) ? cw[rn] + p : ((cw[rn] << (15 - 2 * (4 * (S) + p))) & mask) | (0x3C003C00u & ~mask);  \
+        const ob_half8 aop = __builtin_bit_cast(ob_half8, av);                                                           \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                \
+            acc[rn][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, SRC[rt], acc[rn][rt], 0, 0, 0);                    \
+    }
+    int ks = -1;
+    OB_G3_READ(bopA, 0, 0)
+    if (OB_G3_ABL & 1) { OB_G3_READ(bopB, 0, 1) }
+
+    // One K step as a macro: Q (the step within its quad) and STEADY are literals, so the steady-state loop
+    // has NO branch in it.  Step kc:
+    //   read the second half's operands | 32 MFMAs of the first half | COUNTED wait + raw barrier (tile
+    //   kc + 1 has landed for everyone, every read of tile kc is complete; a __syncthreads would drain the
+    //   younger transfers) | [Q == 0: weights of the next quad] DMA of tile kc + 4 into tile kc's buffer |
+    //   [Q odd: ds_read the next pair's packed words] read the FIRST half of step kc + 1 | 32 MFMAs of the
+    //   second half.
+    // In-order completion: tile kc + 1 (requested in step kc - 3) has landed once at most the transfers of
+    // steps kc - 2 and kc - 1 are outstanding: 4 + 4 + one weight DMA if either opens a quad (Q = 1, 2) --
+    // and everything older, including the next quad's weights (step 4j, first read in step 4j + 3), with it.
+#define OB_G3_STEP(Q, STEADY)                                                                                            \
+    {                                                                                                                    \
+        const int kc = ks + (Q), cur = kc & (OB_G3_BUFS - 1);                                                            \
+        uint32_t cw[RN];                                                                                                 \
+        _Pragma("unroll") for (int rn = 0; rn < RN; ++rn) {                                                              \
+            const uint32_t b16 = (wc[rn][(Q) & 1] >> wsh) & 0xffffu;                                                     \
+            cw[rn] = (b16 & 0x5555u) | ((b16 & 0xAAAAu) << 15);                                                          \
+        }                                                                                                                \
+        uint32_t mask = 0x80008000u;                                                                                     \
+        asm("" : "+s"(mask));                                                                                            \
+        OB_G3_READ(bopB, cur, 1)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        OB_G3_MMA(bopA, 0)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (OB_G3_ABL & 8) {                                                                                             \
+        } else if (STEADY) {                                                                                             \
+            if ((Q) == 1 || (Q) == 2) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                \
+        } else {                                                                                                         \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+        }                                                                                                                \
+        if ((STEADY) && !(OB_G3_ABL & 4)) {                                                                              \
+            if ((Q) == 0) wdma((kc >> 2) + 1);                                                                           \
+            dma(kc + 4);                                                                                                 \
+        }                                                                                                                \
+        if (((Q) & 1) && ((STEADY) || kc + 1 < nk)) {                                                                    \
+            const int pm = (kc + 1) >> 1;                                                                                \
+            const char *wq = wrd + ((pm >> 1) & 1) * 8192 + (pm & 1) * 512;                                              \
+            _Pragma("unroll") for (int rn = 0; rn < RN; ++rn)                                                            \
+                wnx[rn] = *reinterpret_cast<const ob_u32x2 *>(wq + (rn >> 1) * 1024 + (rn & 1) * 256);                   \
+        }                                                                                                                \
+        if ((STEADY) || kc + 1 < nk) { OB_G3_READ(bopA, (kc + 1) & (OB_G3_BUFS - 1), 0) }                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        OB_G3_MMA(bopB, 1)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if ((Q) & 1) {                                                                                                   \
+            /* consume the packed words HERE (32 MFMAs after their ds_read): left pending over the step boundary */     \
+            /* hipcc waits for them with lgkmcnt(0) at the top of the next step, which also drains the operand */       \
+            /* reads just issued for the second half */                                                                  \
+            asm volatile("" : "+v"(wnx[0]), "+v"(wnx[1]), "+v"(wnx[2]), "+v"(wnx[3]));                                   \
+            _Pragma("unroll") for (int rn = 0; rn < RN; ++rn) wc[rn] = wnx[rn];                                          \
+        }                                                                                                                \
+    }
+    ks = 0;
+    for (; ks + 4 < nk; ks += 4) {              // steady state (every quad but the last): all conditions true
+        OB_G3_STEP(0, true)
+        OB_G3_STEP(1, true)
+        OB_G3_STEP(2, true)
+        OB_G3_STEP(3, true)
+    }
+    {                                           // the last quad: its tiles are all requested; drain
+        OB_G3_STEP(0, false)
+        OB_G3_STEP(1, false)
+        OB_G3_STEP(2, false)
+        OB_G3_STEP(3, false)
+    }
+#undef OB_G3_STEP
+#undef OB_G3_MMA
+#undef OB_G3_READ
+
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+        const int nb = n0 + wn * 64 + rn * 16 + 4 * gq;
+        float gn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gn[i] = PARTIAL ? 1.0f : (float)g[min(nb + i, N - 1)];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int t = t0 + wt * 128 + rt * 16 + r;
+            if (t >= T) continue;
+            if (PARTIAL) {
+                if (nb + 3 < N) {
+                    *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = acc[rn][rt];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < N) zp[(int64_t)t * N + nb + i] = acc[rn][rt][i];
+                }
+            } else {
+                _Float16 o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)(ob_round_h(acc[rn][rt][i]) * gn[i]);
+                if (nb + 3 < N) {
+                    const ob_half4 ov = {o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<ob_half4 *>(u + (int64_t)t * N + nb) = ov;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < N) u[(int64_t)t * N + nb + i] = o[i];
+                }
+            }
+        }
+    }
+}
 #undef RN
 #undef RT

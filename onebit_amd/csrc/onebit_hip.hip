@@ -240,13 +240,33 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s);
 static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const void *x, const void *h, const void *g,
                                 void *u, int64_t K, int64_t N, hipStream_t s);
 
+// The LDS-DMA prefill GEMM (ob_gemm3_f16_kernel) consumes pre-scaled activations from the caller's
+// workspace; eligible from ~4 rounds of 256 x 256 tiles over the CUs.  OB_GEMM3=0 disables it (A/B).
+static bool ob_gemm3_ok(int64_t T, int64_t K, int64_t N)
+{
+    static const int env = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
+    // whole quads of K steps; 32-bit byte offsets from the base pointers inside the kernel
+    if (!env || T < 192 || K % (4 * OB_G2_K) != 0 || N % 4 != 0 || T * K * 2 >= ((int64_t)1 << 32) || N * (K / 8) >= ((int64_t)1 << 32)) return false;
+    const int64_t tiles = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + OB_G2_T - 1) / OB_G2_T);
+    return tiles >= 4 * (int64_t)ob_cu_count() || env == 2;
+}
+
+// bytes a call cannot do without (F32: fp32 z is staged in y itself; F16 on the MFMA path: u is staged in
+// y; F16 shapes the MFMA path cannot take (K % 32 != 0) stage fp32 z in the workspace)
+static size_t ob_required_workspace(int64_t T, int64_t K, int64_t N, int dtype)
+{
+    if (T <= 0 || N <= 0) return 0;
+    if (dtype == ONEBIT_F16 && K % 32 != 0) return (size_t)T * (size_t)N * sizeof(float);
+    return 0;
+}
+
 extern "C" size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype)
 {
     if (T <= 0 || N <= 0) return 0;
-    // F32: fp32 z is staged in y itself.  F16 on the MFMA path: u is staged in y.  F16 shapes the
-    // MFMA path cannot take (K % 32 != 0) stage fp32 z in the workspace.
-    if (dtype == ONEBIT_F16 && K % 32 != 0) return (size_t)T * (size_t)N * sizeof(float);
-    return 0;
+    // large prefill calls run fastest with room for the pre-scaled activations a = fp16(x * h) (LDS-DMA
+    // GEMM); a smaller or absent workspace is accepted and selects the register-staged kernel
+    if (dtype == ONEBIT_F16 && K % 32 == 0 && ob_gemm3_ok(T, K, N)) return (size_t)T * (size_t)K * 2;
+    return ob_required_workspace(T, K, N, dtype);
 }
 
 extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, const void *x,
@@ -258,7 +278,7 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
     int rc = ob_check_linear("linear_forward", packed, ldw_bytes, x, h, T, K, N, dtype);
     if (rc) return rc;
     if (flags & ~ONEBIT_FLAG_SKIP_LN) return ob_fail(ONEBIT_E_FLAG, "linear_forward: unknown flags 0x%x", flags);
-    if (workspace_bytes < onebit_linear_workspace_bytes(T, K, N, dtype))
+    if (workspace_bytes < ob_required_workspace(T, K, N, dtype))
         return ob_fail(ONEBIT_E_WSPACE, "linear_forward: workspace too small");
     if (T == 0 || N == 0) return 0;
     if (!g || !y) return ob_fail(ONEBIT_E_ARG, "linear_forward: null pointer");
@@ -272,6 +292,21 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
         } else if (T == 1 && K % 128 == 0 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && K <= 16384) {
             // one token: the persistent decode GEMV (plain prologue) instead of the 16-token tile kernel
             rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
+            if (rc) return rc;
+        } else if (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
+                   ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32)) {
+            // pre-scale once (the fp16 rounding of bitnet.py:113), then the LDS-DMA GEMM on the scaled rows
+            _Float16 *a = (_Float16 *)workspace;
+            const int64_t nvec = T * K / 8;
+            hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, K,
+                               (const _Float16 *)h, a, T, (int)K);
+            static bool attr_set[OB_MAX_DEVICES] = {};
+            ob_set_max_lds_once(ob_gemm3_f16_kernel<false>, attr_set, OB_G3_LDS);
+            const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
+            hipLaunchKernelGGL((ob_gemm3_f16_kernel<false>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
+                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)a, K, (const _Float16 *)g, ubuf, nullptr,
+                               (int)T, (int)K, (int)N, nbn);
+            rc = ob_launch_status("linear_forward(gemm3)");
             if (rc) return rc;
         } else {
             ob_launch_mm16<false>(packed, ldw_bytes, x, K, h, g, ubuf, nullptr, T, K, N, s);

@@ -358,3 +358,15 @@ def test_forward_shape_sweep_hits_every_kernel_route(dev, coracle):
         m.layernorm = torch.nn.Identity()
         u = m(_t(x, dev)).cpu().numpy()
         _check_f16(y, u, y_ref, u_ref, (T, K, N))
+
+
+@pytest.mark.parametrize("env", [{"OB_GEMM3": "2"}, {"OB_GEMM3": "0", "OB_GEMM2": "2"}])
+def test_large_tile_kernels_forced_on_ragged_shapes(dev, env):
+    """The 256 x 256 prefill kernels (LDS-DMA ob_gemm3 / register-staged ob_gemm2) are normally chosen only
+    for grids of >= 4 tiles per CU; forced here (their env switches are read once per process, hence the
+    child interpreter) onto small shapes with ragged last tiles in T and N, against the oracle."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_route_child.py")
+    r = subprocess.run([sys.executable, child], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced-route ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -21,9 +21,11 @@ for (T, K, N) in SHAPES or [(16384, 4096, 11008), (16384, 11008, 4096), (16384, 
     m.weight_scale.data = (0.1 * (0.5 + torch.rand(N, device=dev))).half()
     x = torch.randn(T, K, device=dev).half()
     y = torch.empty(T, N, device=dev, dtype=torch.float16)
+    wsb = 0 if os.environ.get("OB_NO_WS") else lib.onebit_linear_workspace_bytes(T, K, N, 0)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
     def run(flags):
         rc = lib.onebit_linear_forward(m.weight.data_ptr(), m.weight.stride(0), x.data_ptr(), m.input_factor.data_ptr(),
-                                       m.weight_scale.data_ptr(), None, y.data_ptr(), None, None, 0, T, K, N, 0, 1e-5, flags, _stream_ptr(dev))
+                                       m.weight_scale.data_ptr(), None, y.data_ptr(), None, ws.data_ptr() if wsb else None, wsb, T, K, N, 0, 1e-5, flags, _stream_ptr(dev))
         _lib.check(rc, "fwd")
     res = []
     for flags in (1, 0):          # 1 = skip LayerNorm (GEMM only), 0 = full forward
