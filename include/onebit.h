@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 3
+#define ONEBIT_ABI_VERSION 4
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -221,8 +221,14 @@ typedef struct onebit_batch_state {
     void *logits;               /* fp16 [B, vocab] or NULL                                      */
     float *part_val;            /* fp32 [ceil(vocab / 128) * 64] scratch (with next_tokens)     */
     int32_t *part_idx;          /* int32 [ceil(vocab / 128) * 64] scratch (with next_tokens)    */
+    /* optional: fp32 [onebit_batch_stats_floats(model, B)] scratch.  With it the q|k|v GEMM publishes
+     * the per-16-row-tile LayerNorm partials of its three output rows per slot and the attention
+     * workgroups combine them instead of re-reducing the rows (same values up to fp32 rounding of
+     * mean / rstd).  NULL: recompute per workgroup.                                                 */
+    float *qkv_stats;
 } onebit_batch_state_t;
 
+size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);
 int onebit_decode_step_batched(const onebit_model_t *model, const onebit_batch_state_t *state, void *stream);
 
 /* One fused decode GEMV launch (the building block of onebit_decode_step, exposed so that a

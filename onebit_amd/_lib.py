@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libonebit_hip.so")
 
 ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
 _i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
@@ -34,6 +34,7 @@ SYMBOLS = {
     "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),
+    "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),
     "onebit_decode_step": (_int, [_vp, _vp, _vp]),      # (onebit_model_t*, onebit_decode_state_t*, stream)
     "onebit_decode_step_batched": (_int, [_vp, _vp, _vp]),   # (onebit_model_t*, onebit_batch_state_t*, stream)
     "onebit_fused_gemv": (_int, [_vp, _vp, _int, _int, _vp, _vp]),

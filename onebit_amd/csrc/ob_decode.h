@@ -952,7 +952,10 @@ __device__ __forceinline__ float ob_rows_max(float v)
 // (tools/issue_probe.hip), and most of a wave's instructions here do not scale with its share of the
 // positions -- so the single-sequence decode step runs it with 4 waves (one per SIMD), 8 positions
 // per thread and sweep; the batched step (many workgroups per CU anyway) keeps 8 waves.
-template <bool PST, int NTH>
+// BLIND: fetch the first 128 cached positions before the position is known (single sequence: 32 workgroups,
+// latency is everything).  The batched step runs heads x slots workgroups -- 64 KB of blind cache reads each
+// were 64 MB per layer at 32 slots, 13 of the kernel's 16 us -- and reads the position first.
+template <bool PST, int NTH, bool BLIND = true>
 __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 {
     constexpr int NWV = NTH / 64, PG = NTH / 16, NI = 128 / PG;
@@ -967,6 +970,10 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
         A.out += (int64_t)slot * H * D;
         A.kcache += (int64_t)slot * A.slot_stride; A.vcache += (int64_t)slot * A.slot_stride;
         A.pos += slot;
+        if (PST) {      // (batched step: one block of partials per slot)
+            A.st_q += (size_t)slot * (((H * D + 4095) >> 12) * 512);
+            A.st_k += (size_t)slot * (((Hkv * D + 4095) >> 12) * 512); A.st_v += (size_t)slot * (((Hkv * D + 4095) >> 12) * 512);
+        }
     }
     float *red = reinterpret_cast<float *>(smem);                    // [0,96) stats, [96,104) max, [112,120) sum
     _Float16 *q_s = reinterpret_cast<_Float16 *>(smem + 512);         // [128] query (post RoPE), zero padded
@@ -986,13 +993,22 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
     const bool dok = 8 * ds < D;
     const int dcl = dok ? 8 * ds : 0;
     ob_half8 kreg[NI], vreg[NI];
+    int pos_early = 0;
+    if (!BLIND) {
+        pos_early = *A.pos;
+        if (pos_early < 0 || pos_early >= A.max_len) return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int64_t off = (int64_t)min(pg + PG * i, A.max_len - 1) * D + dcl;
-        kreg[i] = *reinterpret_cast<const ob_half8 *>(kbase + off);
-        vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
+        if (BLIND || pg + PG * i < pos_early) {   // rows >= pos are masked below either way (row pos comes from k_s / v_s)
+            kreg[i] = *reinterpret_cast<const ob_half8 *>(kbase + off);
+            vreg[i] = *reinterpret_cast<const ob_half8 *>(vbase + off);
+        } else {
+            kreg[i] = (ob_half8)(_Float16)0; vreg[i] = (ob_half8)(_Float16)0;
+        }
     }
-    const int pos = *A.pos;
+    const int pos = BLIND ? *A.pos : pos_early;
     if (pos < 0 || pos >= A.max_len) return;      // idle slot, or a step past the cache (host error: never write or
                                                   // read beyond the allocation); uniform, before any barrier
     const int L = pos + 1;

@@ -31,7 +31,10 @@ struct ObSkinnyProj {
     _Float16 *u;                  // !PARTIAL: fp16 [T, N]
     float *zp;                    // PARTIAL: fp32 sums [T, N]
     int N, K, tile_end;           // tiles [previous tile_end, tile_end) of the grid
+    float *st;                    // !PARTIAL, optional: per-token LayerNorm partials of u, (sum, M2) per 16-row tile
+                                  // (ob_decode.h ObTileStats layout), token stride ob_tile_stats_floats(N); N % 16 == 0
 };
+__host__ __device__ __forceinline__ int ob_tile_stats_floats(int n) { return ((n + 4095) >> 12) * 512; }
 struct ObSkinnyArgs {
     ObSkinnyProj p[3];
     long long ldx;
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     const _Float16 *__restrict__ x = P.x, *__restrict__ h = P.h, *__restrict__ g = P.g;
     _Float16 *__restrict__ u = P.u;
     float *__restrict__ zp = P.zp;
+    float *__restrict__ stp = P.st;
     const int T = A.T, K = P.K, N = P.N;
     const int tile0 = pi == 0 ? 0 : (pi == 1 ? A.p[0].tile_end : A.p[1].tile_end);
     constexpr int PK = OB_SKINNY_PKT(RT) / RT;  // k elements per phase
@@ -174,8 +178,30 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
 #pragma unroll
         for (int w = 1; w < 8; ++w) z += zr[((w * 4 + rn) * RT + rt) * 64 + sl];
         const int t = rt * 16 + (sl & 15);
-        if (t >= T) continue;
         const int nb = n0 + rn * 16 + 4 * (sl >> 4);
+        if (!PARTIAL && stp) {
+            // the consumer's LayerNorm partials: the 16 rows of tile rn for token t live in the lanes
+            // sl, sl ^ 16, sl ^ 32, sl ^ 48 (4 rows each); every lane of the wave is here (uniform trip count)
+            float o4[4], sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o4[i] = (float)(_Float16)(ob_round_h(z[i]) * (float)g[min(nb + i, N - 1)]);
+                sm += o4[i];
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            const float mu = sm * 0.0625f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m2 = __builtin_fmaf(o4[i] - mu, o4[i] - mu, m2);
+            m2 += __shfl_xor(m2, 16);
+            m2 += __shfl_xor(m2, 32);
+            if (sl < 16 && t < T && n0 + rn * 16 < N) {
+                float *d = stp + (size_t)t * ob_tile_stats_floats(N) + (size_t)((n0 >> 4) + rn) * 2;
+                d[0] = sm; d[1] = m2;
+            }
+        }
+        if (t >= T) continue;
         if (PARTIAL) {
             if (nb + 3 < N && (N & 3) == 0) {
                 *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = z;

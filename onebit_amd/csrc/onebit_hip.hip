@@ -698,6 +698,13 @@ extern "C" size_t onebit_decode_stats_floats(const onebit_model_t *m)
     return ob_stats_layout(m).total;
 }
 
+extern "C" size_t onebit_batch_stats_floats(const onebit_model_t *m, int32_t batch)
+{
+    if (!m || batch <= 0) return 0;
+    const int NQ = m->n_heads * m->head_dim, NK = m->n_kv_heads * m->head_dim;
+    return (size_t)batch * ((size_t)ob_tile_stats_floats(NQ) + 2 * (size_t)ob_tile_stats_floats(NK));
+}
+
 extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
 {
     if (!m || S < 2 || m->n_heads <= 0 || m->max_len <= 0) return 0;
@@ -741,8 +748,11 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     struct P3 { const onebit_proj_t *p[3]; };
     struct U3 { void *u[3]; };
     struct N3 { int64_t n[3]; };
+    struct S3 { float *s[3]; };
+    bool stats_written = false;
     // projections sharing their input: one skinny launch over all their row tiles, or one launch each
-    auto gemm_multi = [&](P3 ps, U3 us, N3 ns, int np, const void *xin, int64_t K, const char *name) -> int {
+    auto gemm_multi = [&](P3 ps, U3 us, N3 ns, S3 ss, int np, const void *xin, int64_t K, const char *name) -> int {
+        stats_written = false;
         bool fuse = true;
         for (int i = 0; i < np; ++i) {
             const onebit_proj_t &p = *ps.p[i];
@@ -766,8 +776,9 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             if (i < np) tiles += (int)((p.N + 63) / 64);
             ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.input_factor,
                        (const _Float16 *)p.weight_scale, (const _Float16 *)xin, (_Float16 *)us.u[j], nullptr, (int)p.N,
-                       (int)K, tiles};
+                       (int)K, tiles, ss.s[j]};
         }
+        stats_written = ss.s[0] != nullptr;
         ka.ldx = K; ka.T = B;
         if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
         else if (B <= 32) ob_launch_skinny<false, 2>(ka, tiles, s);
@@ -789,7 +800,15 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         else hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
         if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
         // 2. q, k, v: one launch when the skinny kernel takes all three
-        if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, 3, st->x, H, "qkv"))) return rc;
+        //    (its epilogue also publishes the LayerNorm partials of the three rows per slot, so the (head, slot)
+        //    attention workgroups do not each re-reduce the whole q / k / v rows)
+        S3 qs = {{nullptr, nullptr, nullptr}};
+        if (st->qkv_stats && NQ % 16 == 0 && NK % 16 == 0) {
+            const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
+            qs.s[0] = st->qkv_stats; qs.s[1] = st->qkv_stats + (size_t)B * fq; qs.s[2] = st->qkv_stats + (size_t)B * (fq + fk);
+        }
+        if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, qs, 3, st->x, H, "qkv"))) return rc;
+        const bool attn_pst = stats_written;
         // 3. attention per (head, slot)
         ObAttnArgs at = {};
         at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
@@ -801,8 +820,11 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
-        if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
-        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
+        if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
+        if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
+        else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
+        else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
+        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
         if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
@@ -813,7 +835,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
-        if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, 2, st->x, H, "gate|up"))) return rc;
+        if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
         ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps};
         hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;

@@ -54,7 +54,7 @@ class _BatchState(ctypes.Structure):
     _fields_ = [("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
-                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp)]
+                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp)]
 
 
 class _FusedIn(ctypes.Structure):
@@ -302,7 +302,7 @@ class BatchedDecodeStep:
     ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
 
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
-                 keep_logits: bool = False):
+                 keep_logits: bool = False, producer_stats: bool = True):
         cfg = model.config
         p = model.lm_head.weight
         if not p.is_cuda:
@@ -345,7 +345,12 @@ class BatchedDecodeStep:
         self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
-                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi)
+                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None)
+        # scratch for the q|k|v LayerNorm partials (published by the GEMM, combined by the attention workgroups)
+        if producer_stats:
+            nst = int(self.lib.onebit_batch_stats_floats(ctypes.byref(self._model), batch))
+            self._qkv_stats = torch.zeros(max(nst, 1), dtype=torch.float32, device=dev)
+            self._state.qkv_stats = self._qkv_stats.data_ptr()
         self.lib.onebit_decode_step_batched.restype = ctypes.c_int
         self.lib.onebit_decode_step_batched.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_BatchState), _vp]
 

@@ -11,16 +11,18 @@ cfg = OneBitLlamaConfig.llama_13b() if name == "13b" else OneBitLlamaConfig.llam
 model = build_synthetic_model(cfg, seed=1, device=dev)
 g = torch.Generator().manual_seed(0)
 rnd = lambda n: torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist()
-cb = ContinuousBatcher(model, max_batch=32, max_len=640)
-for n in [512] * 8 + [16] * 24:
-    cb.add_request(rnd(n), 32)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-out = cb.run()
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-gen = sum(len(v) for v in out.values())
-print("%s job: 32 requests, %d steps (%d graph), %d tokens scheduled (%d generated) in %.3f s -> %.1f generated tok/s"
-      % (name, cb.steps, cb.graph_steps, cb.tokens_scheduled, gen, dt, gen / dt))
-for nslots, max_len in ((32, 160), (32, 640), (8, 160)):
+STEADY_ONLY = bool(os.environ.get("OB_STEADY_ONLY"))           # profiling: just the 32-slot steady-state decode step
+if not STEADY_ONLY:
+    cb = ContinuousBatcher(model, max_batch=32, max_len=640)
+    for n in [512] * 8 + [16] * 24:
+        cb.add_request(rnd(n), 32)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = cb.run()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    gen = sum(len(v) for v in out.values())
+    print("%s job: 32 requests, %d steps (%d graph), %d tokens scheduled (%d generated) in %.3f s -> %.1f generated tok/s"
+          % (name, cb.steps, cb.graph_steps, cb.tokens_scheduled, gen, dt, gen / dt))
+for nslots, max_len in (((32, 160),) if STEADY_ONLY else ((32, 160), (32, 640), (8, 160))):
     cb = ContinuousBatcher(model, max_batch=nslots, max_len=max_len)
     for _ in range(nslots):
         cb.add_request(rnd(16), 100)
