@@ -95,6 +95,11 @@ int onebit_linear_forward(const void *packed, int64_t ldw_bytes, const void *x, 
 int onebit_matmul_partial(const void *packed, int64_t ldw_bytes, const void *x, int64_t ldx,
                           const void *h, float *zp, int64_t T, int64_t K, int64_t N, int dtype,
                           void *stream);
+/* The same with a caller workspace: onebit_linear_workspace_bytes(T, K, N, dtype) bytes let large
+ * calls run the LDS-DMA GEMM on the pre-scaled K slice (a smaller or NULL workspace is accepted). */
+int onebit_matmul_partial_ws(const void *packed, int64_t ldw_bytes, const void *x, int64_t ldx,
+                             const void *h, float *zp, void *workspace, size_t workspace_bytes,
+                             int64_t T, int64_t K, int64_t N, int dtype, void *stream);
 int onebit_scale_layernorm(const float *z, const void *g, const void *bias_or_null, void *y,
                            void *u_or_null, int64_t T, int64_t N, int dtype, float ln_eps,
                            unsigned flags, void *stream);

@@ -27,6 +27,7 @@ SYMBOLS = {
     "onebit_linear_forward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,
                                      _i64, _i64, _i64, _int, _f, _u, _vp]),
     "onebit_matmul_partial": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "onebit_matmul_partial_ws": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, ctypes.c_size_t, _i64, _i64, _i64, _int, _vp]),
     "onebit_scale_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _u, _vp]),
     "onebit_row_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),

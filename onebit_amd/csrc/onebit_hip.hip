@@ -345,9 +345,9 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
     return ob_launch_status("linear_forward(layernorm)");
 }
 
-extern "C" int onebit_matmul_partial(const void *packed, int64_t ldw_bytes, const void *x,
-                                     int64_t ldx, const void *h, float *zp, int64_t T, int64_t K,
-                                     int64_t N, int dtype, void *stream)
+extern "C" int onebit_matmul_partial_ws(const void *packed, int64_t ldw_bytes, const void *x,
+                                        int64_t ldx, const void *h, float *zp, void *workspace, size_t workspace_bytes,
+                                        int64_t T, int64_t K, int64_t N, int dtype, void *stream)
 {
     int rc = ob_check_linear("matmul_partial", packed, ldw_bytes, x, h, T, K, N, dtype);
     if (rc) return rc;
@@ -359,13 +359,33 @@ extern "C" int onebit_matmul_partial(const void *packed, int64_t ldw_bytes, cons
         (void)hipMemsetAsync(zp, 0, (size_t)T * N * 4, s);
         return 0;
     }
-    if (ob_mfma_ok(packed, ldw_bytes, ldx, K, dtype))
+    if (ob_mfma_ok(packed, ldw_bytes, ldx, K, dtype) && ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 &&
+        ob_aligned(workspace, 16) && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32)) {
+        // LDS-DMA GEMM on the pre-scaled K slice (see onebit_linear_forward)
+        _Float16 *a = (_Float16 *)workspace;
+        const int64_t nvec = T * K / 8;
+        hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, ldx,
+                           (const _Float16 *)h, a, T, (int)K);
+        static bool attr_set[OB_MAX_DEVICES] = {};
+        ob_set_max_lds_once(ob_gemm3_f16_kernel<true>, attr_set, OB_G3_LDS);
+        const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
+        hipLaunchKernelGGL((ob_gemm3_f16_kernel<true>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
+                           (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)a, K, nullptr, nullptr, zp,
+                           (int)T, (int)K, (int)N, nbn);
+    } else if (ob_mfma_ok(packed, ldw_bytes, ldx, K, dtype))
         ob_launch_mm16<true>(packed, ldw_bytes, x, ldx, h, nullptr, nullptr, zp, T, K, N, s);
     else if (dtype == ONEBIT_F16)
         ob_launch_simple<_Float16>(packed, ldw_bytes, x, ldx, h, zp, T, K, N, s);
     else
         ob_launch_simple<float>(packed, ldw_bytes, x, ldx, h, zp, T, K, N, s);
     return ob_launch_status("matmul_partial");
+}
+
+extern "C" int onebit_matmul_partial(const void *packed, int64_t ldw_bytes, const void *x,
+                                     int64_t ldx, const void *h, float *zp, int64_t T, int64_t K,
+                                     int64_t N, int dtype, void *stream)
+{
+    return onebit_matmul_partial_ws(packed, ldw_bytes, x, ldx, h, zp, nullptr, 0, T, K, N, dtype, stream);
 }
 
 extern "C" int onebit_scale_layernorm(const float *z, const void *g, const void *bias, void *y,

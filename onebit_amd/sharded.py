@@ -72,10 +72,15 @@ def hip_partial(shard: KShard, x_slice: torch.Tensor) -> torch.Tensor:
     T, Ks = x_slice.shape
     zp = torch.empty((T, shard.out_features), dtype=torch.float32, device=x_slice.device)
     w = shard.weight
+    code = _dtype_code(x_slice.dtype)
+    # room for the pre-scaled slice: large calls then take the LDS-DMA GEMM
+    ws_bytes = lib.onebit_linear_workspace_bytes(T, Ks, shard.out_features, code)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_slice.device) if ws_bytes else None
     with torch.cuda.device(x_slice.device):
-        rc = lib.onebit_matmul_partial(w.data_ptr(), w.stride(0), x_slice.data_ptr(), x_slice.stride(0),
-                                       shard.input_factor.data_ptr(), zp.data_ptr(), T, Ks, shard.out_features,
-                                       _dtype_code(x_slice.dtype), _stream_ptr(x_slice.device))
+        rc = lib.onebit_matmul_partial_ws(w.data_ptr(), w.stride(0), x_slice.data_ptr(), x_slice.stride(0),
+                                          shard.input_factor.data_ptr(), zp.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, ws_bytes, T, Ks, shard.out_features,
+                                          code, _stream_ptr(x_slice.device))
     _lib.check(rc, "onebit_matmul_partial")
     return zp
 

@@ -219,3 +219,51 @@ def test_native_batched_step_32_slots_13b_layers():
             j = next(i for i in range(m) if got[i] != ref[i])
             lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
             assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
+
+
+def test_k_sharded_prefill_full_size_vs_oracle(coracle):
+    """The K-sharded form of config 3 at full size (T = 16384, 4096 -> 11008 as two K slices of 2048 passed
+    in place): onebit_matmul_partial_ws with room for the pre-scaled slice (the LDS-DMA GEMM in its fp32
+    partial-sum form), summed, onebit_scale_layernorm -- 40 token rows against the oracle, and the
+    workspace-less call (register-staged kernel) must give the same sums up to fp32 accumulation order."""
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    K, N, T, S = 4096, 11008, 8 * 2048, 2
+    m, packed, h, g = _mk(K, N, 33, dev)
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn(T, K, generator=gen).half()
+    xd = x.to(dev)
+    Ks = K // S
+    zsum = torch.zeros(T, N, dtype=torch.float32, device=dev)
+    wt, ht, gt = m.weight.data, m.input_factor.data, m.weight_scale.data
+    ws_bytes = lib.onebit_linear_workspace_bytes(T, Ks, N, 0)
+    assert ws_bytes >= T * Ks * 2          # this shape is eligible for the LDS-DMA kernel
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    for s in range(S):
+        zp = torch.empty(T, N, dtype=torch.float32, device=dev)
+        rc = lib.onebit_matmul_partial_ws(wt.data_ptr() + s * Ks // 8, K // 8, xd.data_ptr() + 2 * s * Ks, K,
+                                          ht.data_ptr() + 2 * s * Ks, zp.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          T, Ks, N, 0, _stream_ptr(dev))
+        _lib.check(rc, "matmul_partial_ws")
+        if s == 0:
+            z0 = torch.empty(T, N, dtype=torch.float32, device=dev)
+            rc = lib.onebit_matmul_partial(wt.data_ptr(), K // 8, xd.data_ptr(), K, ht.data_ptr(), z0.data_ptr(),
+                                           T, Ks, N, 0, _stream_ptr(dev))
+            _lib.check(rc, "matmul_partial")
+            # same products, different fp32 summation order
+            assert float((z0 - zp).abs().max()) <= 1e-5 * max(1.0, float(zp.abs().max()))
+        zsum += zp
+    y = torch.empty(T, N, dtype=torch.float16, device=dev)
+    u = torch.empty(T, N, dtype=torch.float16, device=dev)
+    rc = lib.onebit_scale_layernorm(zsum.data_ptr(), gt.data_ptr(), None, y.data_ptr(), u.data_ptr(),
+                                    T, N, 0, 1e-5, 0, _stream_ptr(dev))
+    _lib.check(rc, "scale_layernorm")
+    rows = sorted(set(np.random.default_rng(4).integers(0, T, 36).tolist()) | {0, 255, 256, T - 1})
+    y_ref, u_ref = coracle.forward_f16(packed, x[rows].numpy(), h, g, None, return_pre_ln=True)
+    un, yn = u[rows].cpu().numpy(), y[rows].cpu().numpy()
+    for i, r in enumerate(rows):
+        _check_u(un[i], u_ref[i], "row %d" % r)
+        rel = np.linalg.norm(yn[i].astype(np.float32) - y_ref[i].astype(np.float32)) / np.linalg.norm(y_ref[i].astype(np.float32))
+        assert rel <= 1e-3, (r, rel)
