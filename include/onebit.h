@@ -132,6 +132,16 @@ int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *
 int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *act, int64_t T, int64_t I, float ln_eps,
                        void *stream);
 
+/* Prefill glue between the q|k|v projections (called with ONEBIT_FLAG_SKIP_LN) and attention, fp16:
+ * LayerNorm of the three rows (bitnet.py:118), RoPE on q and k (modeling_bitllama.py:175-181, every op
+ * rounded to fp16) and the head transpose (:478-480) in one pass over T = B * S token rows.
+ * q -> [B, n_heads, S, head_dim]; k, v -> cache rows [b][kv head][past_len + s][head_dim] of caches
+ * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim].           */
+int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                         void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
+                         int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
+                         float ln_eps, void *stream);
+
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's
  * BitLlamaForCausalLMInf (modeling_bitllama.py:1512; decoder layer :856-928, attention

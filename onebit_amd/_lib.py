@@ -33,6 +33,7 @@ SYMBOLS = {
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp]),
     "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),
     "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),

@@ -152,6 +152,96 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
 }
 
 // ---------------------------------------------------------------------------------------------
+// Prefill glue between the q|k|v projections and the attention kernel, one workgroup per token row:
+// LayerNorm of the three pre-LayerNorm rows (bitnet.py:118 -- the projections are called with
+// ONEBIT_FLAG_SKIP_LN), RoPE on q and k (apply_rotary_pos_emb, modeling_bitllama.py:175-181: q*cos +
+// rotate_half(q)*sin, every op rounded to fp16) and the [B, S, heads, D] -> [B, heads, S, D] transpose
+// (:478-480) in one pass: q goes to its own [B, H, S, D] tensor, k and v straight into the KV cache rows
+// [slot][kv head][past + s][D].  Replaces one LayerNorm kernel per projection plus ~8 elementwise torch
+// kernels (cat / mul / add / neg / copy: 37 ms of a 262 ms 7B prefill of 8 x 2048 tokens).
+// ---------------------------------------------------------------------------------------------
+struct ObQkvRopeArgs {
+    const _Float16 *u_q, *u_k, *u_v;     // [T, H*D], [T, Hkv*D], [T, Hkv*D] pre-LayerNorm, T = B * S
+    const _Float16 *cos, *sin;           // [max_pos, D]
+    _Float16 *q;                         // [B, H, S, D]
+    _Float16 *kcache, *vcache;           // [slots, Hkv, max_len, D]
+    int S, H, Hkv, D, past, max_len;
+    float ln_eps;
+};
+
+__global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkvRopeArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float red[128];
+    const int tid = threadIdx.x, D = A.D, half = D >> 1;
+    const int NQ = A.H * D, NK = A.Hkv * D;
+    const int t = blockIdx.x, b = t / A.S, sp = t - b * A.S, pos = A.past + sp;
+    const _Float16 *uq = A.u_q + (int64_t)t * NQ, *uk = A.u_k + (int64_t)t * NK, *uv = A.u_v + (int64_t)t * NK;
+    // thread owns 8 consecutive elements of each vector per pass (D % 8 == 0: never straddles a head), and
+    // fetches their rotate_half partners (same head, d +- D/2) alongside
+    ob_half8 q8[OB_DEC_MAXV], qp8[OB_DEC_MAXV], k8[OB_DEC_MAXV], kp8[OB_DEC_MAXV], v8[OB_DEC_MAXV];
+    bool vq[OB_DEC_MAXV], vk[OB_DEC_MAXV];
+#pragma unroll
+    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        const int base = (v * OB_DEC_THREADS + tid) * 8;
+        vq[v] = base < NQ; vk[v] = base < NK;
+        const int bq = vq[v] ? base : 0, bk = vk[v] ? base : 0;
+        const int dq = bq % D, dk = bk % D;
+        q8[v] = *reinterpret_cast<const ob_half8 *>(uq + bq);
+        qp8[v] = *reinterpret_cast<const ob_half8 *>(uq + bq + (dq < half ? half : -half));
+        k8[v] = *reinterpret_cast<const ob_half8 *>(uk + bk);
+        kp8[v] = *reinterpret_cast<const ob_half8 *>(uk + bk + (dk < half ? half : -half));
+        v8[v] = *reinterpret_cast<const ob_half8 *>(uv + bk);
+    }
+    const float cq = (float)uq[0], ck = (float)uk[0], cv = (float)uv[0];
+    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        if (vq[v]) ob_stats8(q8[v], cq, a2[0], a2[1]);
+        if (vk[v]) { ob_stats8(k8[v], ck, a2[2], a2[3]); ob_stats8(v8[v], cv, a2[4], a2[5]); }
+    }
+    float st[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st[i] = a2[i][0] + a2[i][1];
+    ob_block_sum_n<6, OB_DEC_WAVES>(st, red);
+    float mq, rq, mk, rk, mv, rv;
+    ob_ln_stats(st[0], st[1], cq, NQ, A.ln_eps, mq, rq);
+    ob_ln_stats(st[2], st[3], ck, NK, A.ln_eps, mk, rk);
+    ob_ln_stats(st[4], st[5], cv, NK, A.ln_eps, mv, rv);
+    const _Float16 *cosr = A.cos + (int64_t)pos * D, *sinr = A.sin + (int64_t)pos * D;
+#pragma unroll
+    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        const int base = (v * OB_DEC_THREADS + tid) * 8;
+        if (vq[v]) {
+            const int hd = base / D, d0 = base - hd * D;
+            const ob_half8 c8 = *reinterpret_cast<const ob_half8 *>(cosr + d0), s8 = *reinterpret_cast<const ob_half8 *>(sinr + d0);
+            ob_half8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x0 = ob_ln_apply((float)q8[v][i], mq, rq), x1 = ob_ln_apply((float)qp8[v][i], mq, rq);
+                const float xr = d0 < half ? -x1 : x1;
+                o[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
+            }
+            *reinterpret_cast<ob_half8 *>(A.q + (((int64_t)b * A.H + hd) * A.S + sp) * D + d0) = o;
+        }
+        if (vk[v]) {
+            const int hd = base / D, d0 = base - hd * D;
+            const ob_half8 c8 = *reinterpret_cast<const ob_half8 *>(cosr + d0), s8 = *reinterpret_cast<const ob_half8 *>(sinr + d0);
+            ob_half8 ok, ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x0 = ob_ln_apply((float)k8[v][i], mk, rk), x1 = ob_ln_apply((float)kp8[v][i], mk, rk);
+                const float xr = d0 < half ? -x1 : x1;
+                ok[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
+                ov[i] = (_Float16)ob_ln_apply((float)v8[v][i], mv, rv);
+            }
+            const int64_t off = (((int64_t)b * A.Hkv + hd) * A.max_len + pos) * D + d0;
+            *reinterpret_cast<ob_half8 *>(A.kcache + off) = ok;
+            *reinterpret_cast<ob_half8 *>(A.vcache + off) = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batched lm_head + greedy sampling (modeling_bitllama.py:1610-1611, generation/utils.py:2540):
 // logits[b][v] = fp16( sum_k x[b][k] * W[v][k] ), next[b] = argmax_v (first index on ties).
 // The fp16 lm_head matrix (2 V H bytes: 262 MB at 7B) is streamed ONCE per step for all B <= 64

@@ -695,6 +695,28 @@ extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *ac
     return ob_launch_status("rows_swiglu");
 }
 
+extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                                    void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
+                                    int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
+                                    float ln_eps, void *stream)
+{
+    if (B < 0 || S < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || past_len < 0)
+        return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: bad size");
+    if (head_dim % 16 != 0 || (int64_t)n_heads * head_dim > OB_DEC_MAXV * OB_DEC_THREADS * 8 || n_kv_heads > n_heads)
+        return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope: heads %d / %d x %d", n_heads, n_kv_heads, head_dim);
+    if (past_len + S > max_len || past_len + S > max_pos)
+        return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope: %lld + %lld tokens beyond the cache (%lld) or the rope tables (%lld)",
+                       (long long)past_len, (long long)S, (long long)max_len, (long long)max_pos);
+    if (B == 0 || S == 0) return 0;
+    if (!u_q || !u_k || !u_v || !cos || !sin || !q || !k_cache || !v_cache) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: null pointer");
+    if (B * S > 0x7fffffffLL || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: dimension too large");
+    ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
+                       (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, (int)S, n_heads, n_kv_heads, head_dim, (int)past_len,
+                       (int)max_len, ln_eps};
+    hipLaunchKernelGGL(ob_qkv_rope_kernel, dim3((unsigned)(B * S)), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    return ob_launch_status("rows_qkv_rope");
+}
+
 // Tile partials: one slot per pre-LayerNorm vector of a layer (q, k, v, o, gate, up, down), each
 // 2 floats per 16-row tile, padded to whole blocks of 256 tiles (the consumers read whole blocks).
 struct ObStatsLayout { size_t off[7]; size_t total; };

@@ -262,7 +262,25 @@ class OneBitLlamaForCausalLM(nn.Module):
             if u_down is not None:
                 h, x = res_ln_rms(h, u_down, layer.input_layernorm.weight)
             att = layer.self_attn
-            u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
+            if (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
+                    and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()):
+                # q|k|v LayerNorm + RoPE + head transpose in one pass (onebit_rows_qkv_rope): k, v land in
+                # the cache rows, q in [B, heads, S, D]; then the fused causal attention
+                Hh, Hkv, D = att.num_heads, att.num_key_value_heads, att.head_dim
+                u_q, u_k, u_v = att.q_proj.pre_layernorm(x), att.k_proj.pre_layernorm(x), att.v_proj.pre_layernorm(x)
+                q = torch.empty((B, Hh, S, D), dtype=x.dtype, device=x.device)
+                kc, vc = kv
+                with torch.cuda.device(h.device):
+                    _lib.check(lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                        q.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past,
+                                                        kc.shape[2], cos.shape[0], 1e-5, sp), "onebit_rows_qkv_rope")
+                keys, vals = kc[:B, :, :S], vc[:B, :, :S]
+                if Hkv != Hh:
+                    keys, vals = keys.repeat_interleave(Hh // Hkv, dim=1), vals.repeat_interleave(Hh // Hkv, dim=1)
+                o = nn.functional.scaled_dot_product_attention(q, keys, vals, is_causal=True)
+                u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))
+            else:
+                u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
             h, x = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight)
             u_g, u_u = layer.mlp.gate_proj.pre_layernorm(x), layer.mlp.up_proj.pre_layernorm(x)
             act = torch.empty_like(u_g)

@@ -145,3 +145,72 @@ def test_tensor_parallel_prefill_world1_matches_module_path():
     assert float((got - ref).abs().max()) <= 6e-3 * scale
     assert tp.exchanges == 2 * cfg.num_hidden_layers
     assert tp.kv[0][0].shape == (3, 4, 37, cfg.head_dim)
+
+
+def test_rows_qkv_rope_matches_module_ops():
+    """onebit_rows_qkv_rope (LayerNorm of the q|k|v rows + RoPE + head transpose, k / v into cache rows at
+    past_len) against the module path's torch ops (F.layer_norm, the rotate_half formula of
+    modeling_bitllama.py:175-181 with every op rounded to fp16), grouped-query shape, batch 3, past 5."""
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, S, Hh, Hkv, D, past, max_len, max_pos = 3, 21, 8, 2, 64, 5, 40, 64
+    g = torch.Generator().manual_seed(11)
+    u_q = (0.3 * torch.randn(B * S, Hh * D, generator=g) + 0.05).half().to(dev)
+    u_k = (0.2 * torch.randn(B * S, Hkv * D, generator=g) - 0.1).half().to(dev)
+    u_v = (0.5 * torch.randn(B * S, Hkv * D, generator=g)).half().to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(torch.arange(max_pos).float(), inv)
+    emb = torch.cat((fr, fr), dim=-1)
+    cos, sin = emb.cos().half().to(dev), emb.sin().half().to(dev)
+    q = torch.zeros(B, Hh, S, D, dtype=torch.float16, device=dev)
+    kc = torch.zeros(B + 1, Hkv, max_len, D, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    rc = lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(),
+                                  kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past, max_len, max_pos, 1e-5, _stream_ptr(dev))
+    _lib.check(rc, "rows_qkv_rope")
+
+    def rot(x):
+        return torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1)
+    c, s = cos[past:past + S][None, None], sin[past:past + S][None, None]
+    lq = torch.nn.functional.layer_norm(u_q, (Hh * D,)).view(B, S, Hh, D).transpose(1, 2)
+    lk = torch.nn.functional.layer_norm(u_k, (Hkv * D,)).view(B, S, Hkv, D).transpose(1, 2)
+    lv = torch.nn.functional.layer_norm(u_v, (Hkv * D,)).view(B, S, Hkv, D).transpose(1, 2)
+    q_ref = (lq * c) + (rot(lq) * s)
+    k_ref = (lk * c) + (rot(lk) * s)
+    # the LayerNorm statistics are fp32 sums in a different order: a handful of elements move by one fp16 ulp
+    for got, ref in ((q, q_ref), (kc[:B, :, past:past + S], k_ref), (vc[:B, :, past:past + S], lv)):
+        d = (got.float() - ref.float()).abs()
+        ulp = torch.clamp(ref.float().abs(), min=2.0 ** -14) * 2.0 ** -10
+        assert float((d / ulp).max()) <= 2.001
+        assert float((d > 0).float().mean()) <= 0.02
+    # nothing outside rows [past, past + S) of slots [0, B) was touched
+    assert float(kc[B].abs().max()) == 0 and float(kc[:, :, :past].abs().max()) == 0 and float(kc[:, :, past + S:].abs().max()) == 0
+    # error behaviour: tokens beyond the cache
+    assert lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(),
+                                    kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, 30, max_len, max_pos, 1e-5, _stream_ptr(dev)) != 0
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_fused_glue_with_sdpa_uses_rows_qkv_rope_within_tolerance(golden_dir, name):
+    """set_fused_glue + set_attention("sdpa"): the prefill route bench.py's prefill_model field times
+    (q|k|v through onebit_rows_qkv_rope into the cache, fused causal attention) against the reference's
+    recorded prefill logits, then two decode tokens on top of the cache that route filled."""
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, f"model_tiny_{name}.npz"))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    model = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")})
+    model = model.to(dev).eval().set_fused_glue(True).set_attention("sdpa")
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    ref16, ref32 = z["prefill_logits_f16"], z["prefill_logits_f32"]
+    tol = max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
+    cache = model.new_cache(1, ids.shape[1] + 4)
+    lg = model(ids, cache).cpu().numpy()
+    assert np.abs(lg - ref16).max() <= tol
+    toks = z["greedy_f16"][0]
+    lg2 = model(torch.tensor([[int(toks[0]), int(toks[1])]], device=dev), cache).cpu().numpy()
+    assert np.abs(lg2[0, 0] - z["decode_logits_f16"][0][0]).max() <= tol
+    assert np.abs(lg2[0, 1] - z["decode_logits_f16"][0][1]).max() <= tol
