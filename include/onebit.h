@@ -47,6 +47,9 @@ extern "C" {
 
 /* flags for onebit_linear_forward */
 #define ONEBIT_FLAG_SKIP_LN   1u   /* y receives u = (W.(h*x))*g, LayerNorm (and bias) skipped */
+#define ONEBIT_FLAG_PRESCALED 4u   /* x already holds fp16(x * h) (bitnet.py:113 done by the producer of x:
+                                      onebit_rows_res_ln_rms / onebit_rows_swiglu with h_next); h is not read.
+                                      Only where onebit_linear_prescaled_ok(T, K, N, dtype) returns 1.        */
 
 int onebit_abi_version(void);
 const char *onebit_last_error(void);
@@ -124,23 +127,31 @@ int onebit_normalize_rows(const void *u, const float *mean, const float *rstd, c
  * a BitLinearInf then fuses with what the decoder layer does next (modeling_bitllama.py:912-918,
  * 76-81, 257), one pass over the rows instead of five:
  * onebit_rows_res_ln_rms: r = hres_in + LayerNorm(u_prev);  hres_out = r;  x = RMSNorm(r) * rms_w
- * onebit_rows_swiglu:     act = silu(LayerNorm(u_gate)) * LayerNorm(u_up)
+ *                         and, for i < n_scaled (<= 3): x_scaled[i] = fp16(x * h_next[i]) -- the input
+ *                         scaling of the projections that consume x, for ONEBIT_FLAG_PRESCALED calls
+ *                         (x may be NULL when n_scaled > 0)
+ * onebit_rows_swiglu:     act = silu(LayerNorm(u_gate)) * LayerNorm(u_up); with h_next: act = fp16(act * h_next)
  * All tensors fp16, [T, H] / [T, I] contiguous; H, I % 8 == 0 and <= 16384.
  */
 int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
-                           void *x, int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
-int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *act, int64_t T, int64_t I, float ln_eps,
-                       void *stream);
+                           void *x_or_null, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
+                           int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
+int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next_or_null, void *act, int64_t T,
+                       int64_t I, float ln_eps, void *stream);
+int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype);
 
 /* Prefill glue between the q|k|v projections (called with ONEBIT_FLAG_SKIP_LN) and attention, fp16:
  * LayerNorm of the three rows (bitnet.py:118), RoPE on q and k (modeling_bitllama.py:175-181, every op
  * rounded to fp16) and the head transpose (:478-480) in one pass over T = B * S token rows.
  * q -> [B, n_heads, S, head_dim]; k, v -> cache rows [b][kv head][past_len + s][head_dim] of caches
- * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim].           */
+ * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim].
+ * ONEBIT_FLAG_Q_TOKEN_MAJOR: q stays [B, S, n_heads, head_dim] (a caller whose attention kernel takes
+ * strided views then gets its output in token-major rows, ready for o_proj without a transpose copy).  */
+#define ONEBIT_FLAG_Q_TOKEN_MAJOR 0x2u
 int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
                          void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
                          int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
-                         float ln_eps, void *stream);
+                         float ln_eps, unsigned flags, void *stream);
 
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libonebit_hip.so")
 
 ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
+FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
+FLAG_PRESCALED = 4
 ABI_VERSION = 4
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
@@ -31,9 +33,10 @@ SYMBOLS = {
     "onebit_scale_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _u, _vp]),
     "onebit_row_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
-    "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp]),
-    "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _i64, _i64, _f, _vp]),
-    "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _f, _f, _vp]),
+    "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    "onebit_linear_prescaled_ok": (_int, [_i64, _i64, _i64, _int]),
+    "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),
     "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),

@@ -144,7 +144,22 @@ class BitLinearInf(nn.Module):
             raise RuntimeError("pre_layernorm: the bias is added after the LayerNorm; use forward")
         return self.forward(input, _pre_ln=True)
 
-    def forward(self, input: torch.Tensor, _pre_ln: bool = False) -> torch.Tensor:
+    def prescaled_ok(self, T: int, dtype=torch.float16) -> bool:
+        """True when a T-row call of this layer may consume pre-scaled activations
+        (``pre_layernorm_prescaled``): it takes the LDS-DMA GEMM, which reads fp16(x * h) rows."""
+        if self.bias is not None or dtype != torch.float16 or self.weight_scale.dtype != torch.float16:
+            return False
+        return bool(_lib.load().onebit_linear_prescaled_ok(T, self.in_features, self.out_features, _dtype_code(dtype)))
+
+    def pre_layernorm_prescaled(self, a: torch.Tensor) -> torch.Tensor:
+        """``pre_layernorm`` on activations the producer already scaled: ``a = fp16(x * input_factor)``
+        (onebit_rows_res_ln_rms / onebit_rows_swiglu with ``h_next``), ONEBIT_FLAG_PRESCALED.  Only where
+        ``prescaled_ok(T)``; the C side refuses the flag elsewhere."""
+        if self.bias is not None:
+            raise RuntimeError("pre_layernorm: the bias is added after the LayerNorm; use forward")
+        return self.forward(a, _pre_ln=True, _prescaled=True)
+
+    def forward(self, input: torch.Tensor, _pre_ln: bool = False, _prescaled: bool = False) -> torch.Tensor:
         K, N = self.in_features, self.out_features
         if input.shape[-1] != K:
             raise RuntimeError(f"BitLinearInf: expected last dim {K}, got {tuple(input.shape)}")
@@ -180,7 +195,11 @@ class BitLinearInf(nn.Module):
         b = None if self.bias is None else self.bias.to(cdt).contiguous()
         y = torch.empty((T, N), dtype=cdt, device=x.device)
         lib = _lib.load()
-        ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
+        if _prescaled:
+            flags |= _lib.FLAG_PRESCALED
+            ws_bytes = 0                                   # the scaled rows ARE the input
+        else:
+            ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
         with torch.cuda.device(x.device):
             rc = lib.onebit_linear_forward(

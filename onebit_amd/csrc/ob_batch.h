@@ -18,9 +18,14 @@ struct ObBNormArgs {
     const _Float16 *g_prev;       //   and its weight_scale [H]
     const _Float16 *rms_w;        // [H]
     _Float16 *hres_out;           // [B, H]
-    _Float16 *x;                  // [B, H]
+    _Float16 *x;                  // [B, H] (may be NULL when only the scaled outputs are wanted)
     int H;
     float rms_eps, ln_eps;
+    // up to 3 consumers' pre-scaled activations a_i = fp16(x * h_i) (the rounding of bitnet.py:113 done by the
+    // producer: the consuming projections are then called with ONEBIT_FLAG_PRESCALED and skip their own pass)
+    const _Float16 *h_next[3];
+    _Float16 *x_scaled[3];
+    int n_scaled;
 };
 
 template <bool EMBED>
@@ -96,7 +101,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
             ob_half8 t;
 #pragma unroll
             for (int i = 0; i < 8; ++i) t[i] = (_Float16)__builtin_fmaf((float)hv[v][i], rs, 0.0f);
-            *reinterpret_cast<ob_half8 *>(A.x + row + base) = w * t;
+            const ob_half8 xv = w * t;
+            if (A.x) *reinterpret_cast<ob_half8 *>(A.x + row + base) = xv;
+            for (int j = 0; j < A.n_scaled; ++j)
+                *reinterpret_cast<ob_half8 *>(A.x_scaled[j] + row + base) = xv * *reinterpret_cast<const ob_half8 *>(A.h_next[j] + base);
             *reinterpret_cast<ob_half8 *>(A.hres_out + row + base) = hv[v];
         }
     }
@@ -107,6 +115,7 @@ struct ObBSwigluArgs {
     _Float16 *act;                   // [B, I]
     int I;
     float ln_eps;
+    const _Float16 *h_next;          // optional: act <- fp16(act * h_next), the consumer's pre-scaled activations
 };
 
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSwigluArgs A)
@@ -146,7 +155,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)gh, -1.44269504088896341f, 0.0f));
                 sg[i] = (_Float16)__builtin_fmaf((float)gh, __builtin_amdgcn_rcpf(1.0f + e), 0.0f);
             }
-            *reinterpret_cast<ob_half8 *>(A.act + row + base) = sg * up;
+            ob_half8 av = sg * up;                                               // act_fn(gate) * up -> fp16
+            if (A.h_next) av = av * *reinterpret_cast<const ob_half8 *>(A.h_next + base);       // fp16(act * h), bitnet.py:113
+            *reinterpret_cast<ob_half8 *>(A.act + row + base) = av;
         }
     }
 }
@@ -163,9 +174,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
 struct ObQkvRopeArgs {
     const _Float16 *u_q, *u_k, *u_v;     // [T, H*D], [T, Hkv*D], [T, Hkv*D] pre-LayerNorm, T = B * S
     const _Float16 *cos, *sin;           // [max_pos, D]
-    _Float16 *q;                         // [B, H, S, D]
+    _Float16 *q;                         // [B, H, S, D], or [B, S, H, D] with q_bshd (the caller then hands the
+                                         // attention kernel a transposed view and gets its output in token-major rows)
     _Float16 *kcache, *vcache;           // [slots, Hkv, max_len, D]
-    int S, H, Hkv, D, past, max_len;
+    int S, H, Hkv, D, past, max_len, q_bshd;
     float ln_eps;
 };
 
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
                 const float xr = d0 < half ? -x1 : x1;
                 o[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
             }
-            *reinterpret_cast<ob_half8 *>(A.q + (((int64_t)b * A.H + hd) * A.S + sp) * D + d0) = o;
+            _Float16 *qd = A.q_bshd ? A.q + (int64_t)t * NQ + base : A.q + (((int64_t)b * A.H + hd) * A.S + sp) * D + d0;
+            *reinterpret_cast<ob_half8 *>(qd) = o;
         }
         if (vk[v]) {
             const int hd = base / D, d0 = base - hd * D;

@@ -277,7 +277,12 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
 {
     int rc = ob_check_linear("linear_forward", packed, ldw_bytes, x, h, T, K, N, dtype);
     if (rc) return rc;
-    if (flags & ~ONEBIT_FLAG_SKIP_LN) return ob_fail(ONEBIT_E_FLAG, "linear_forward: unknown flags 0x%x", flags);
+    if (flags & ~(ONEBIT_FLAG_SKIP_LN | ONEBIT_FLAG_PRESCALED)) return ob_fail(ONEBIT_E_FLAG, "linear_forward: unknown flags 0x%x", flags);
+    const bool prescaled = (flags & ONEBIT_FLAG_PRESCALED) != 0;
+    if (prescaled && !(onebit_linear_prescaled_ok(T, K, N, dtype) && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && ob_aligned(x, 16) &&
+                       N * ldw_bytes < ((int64_t)1 << 32)))
+        return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call that does not take the LDS-DMA GEMM "
+                                      "(ask onebit_linear_prescaled_ok first)");
     if (workspace_bytes < ob_required_workspace(T, K, N, dtype))
         return ob_fail(ONEBIT_E_WSPACE, "linear_forward: workspace too small");
     if (T == 0 || N == 0) return 0;
@@ -293,18 +298,22 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             // one token: the persistent decode GEMV (plain prologue) instead of the 16-token tile kernel
             rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
             if (rc) return rc;
-        } else if (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
-                   ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32)) {
-            // pre-scale once (the fp16 rounding of bitnet.py:113), then the LDS-DMA GEMM on the scaled rows
-            _Float16 *a = (_Float16 *)workspace;
-            const int64_t nvec = T * K / 8;
-            hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, K,
-                               (const _Float16 *)h, a, T, (int)K);
+        } else if (prescaled || (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
+                                 ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32))) {
+            // pre-scale once (the fp16 rounding of bitnet.py:113) -- unless the producer of x already did
+            // (ONEBIT_FLAG_PRESCALED) --, then the LDS-DMA GEMM on the scaled rows
+            const _Float16 *a = (const _Float16 *)x;
+            if (!prescaled) {
+                const int64_t nvec = T * K / 8;
+                hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, K,
+                                   (const _Float16 *)h, (_Float16 *)workspace, T, (int)K);
+                a = (const _Float16 *)workspace;
+            }
             static bool attr_set[OB_MAX_DEVICES] = {};
             ob_set_max_lds_once(ob_gemm3_f16_kernel<false>, attr_set, OB_G3_LDS);
             const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
             hipLaunchKernelGGL((ob_gemm3_f16_kernel<false>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
-                               (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)a, K, (const _Float16 *)g, ubuf, nullptr,
+                               (const uint32_t *)packed, ldw_bytes / 4, a, K, (const _Float16 *)g, ubuf, nullptr,
                                (int)T, (int)K, (int)N, nbn);
             rc = ob_launch_status("linear_forward(gemm3)");
             if (rc) return rc;
@@ -668,38 +677,53 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
 }
 
 extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
-                                      void *x, int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
+                                      void *x, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
+                                      int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
 {
-    if (T < 0 || H <= 0) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: bad size");
+    if (T < 0 || H <= 0 || n_scaled < 0 || n_scaled > 3) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: bad size");
     if (H % 8 != 0 || H > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_res_ln_rms: H = %lld", (long long)H);
     if (T == 0) return 0;
-    if (!hres_in || !u_prev || !rms_w || !hres_out || !x) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null pointer");
+    if (!hres_in || !u_prev || !rms_w || !hres_out || (!x && n_scaled == 0) || (n_scaled > 0 && (!h_next || !x_scaled)))
+        return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null pointer");
     if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: dimension too large");
     ObBNormArgs a = {};
     a.hres_in = (const _Float16 *)hres_in; a.u_prev = (const _Float16 *)u_prev; a.rms_w = (const _Float16 *)rms_w;
     a.hres_out = (_Float16 *)hres_out; a.x = (_Float16 *)x; a.H = (int)H; a.rms_eps = rms_eps; a.ln_eps = ln_eps;
+    a.n_scaled = n_scaled;
+    for (int i = 0; i < n_scaled; ++i) {
+        if (!h_next[i] || !x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null scaled output %d", i);
+        a.h_next[i] = (const _Float16 *)h_next[i]; a.x_scaled[i] = (_Float16 *)x_scaled[i];
+    }
     hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
     return ob_launch_status("rows_res_ln_rms");
 }
 
-extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, void *act, int64_t T, int64_t I, float ln_eps,
-                                  void *stream)
+extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next, void *act, int64_t T, int64_t I,
+                                  float ln_eps, void *stream)
 {
     if (T < 0 || I <= 0) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: bad size");
     if (I % 8 != 0 || I > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_swiglu: I = %lld", (long long)I);
     if (T == 0) return 0;
     if (!u_gate || !u_up || !act) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: null pointer");
     if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: dimension too large");
-    ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps};
+    ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps, (const _Float16 *)h_next};
     hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
     return ob_launch_status("rows_swiglu");
+}
+
+// 1 when a call of this shape may pass ONEBIT_FLAG_PRESCALED (it would take the LDS-DMA GEMM, which consumes
+// pre-scaled rows); the other kernels multiply by h on the way in and cannot skip it
+extern "C" int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype)
+{
+    return dtype == ONEBIT_F16 && T > 0 && K > 0 && N > 0 && K % 32 == 0 && ob_gemm3_ok(T, K, N) ? 1 : 0;
 }
 
 extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
                                     void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
                                     int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
-                                    float ln_eps, void *stream)
+                                    float ln_eps, unsigned flags, void *stream)
 {
+    if (flags & ~ONEBIT_FLAG_Q_TOKEN_MAJOR) return ob_fail(ONEBIT_E_FLAG, "rows_qkv_rope: unknown flags 0x%x", flags);
     if (B < 0 || S < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || past_len < 0)
         return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: bad size");
     if (head_dim % 16 != 0 || (int64_t)n_heads * head_dim > OB_DEC_MAXV * OB_DEC_THREADS * 8 || n_kv_heads > n_heads)
@@ -712,7 +736,7 @@ extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void
     if (B * S > 0x7fffffffLL || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: dimension too large");
     ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
                        (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, (int)S, n_heads, n_kv_heads, head_dim, (int)past_len,
-                       (int)max_len, ln_eps};
+                       (int)max_len, (flags & ONEBIT_FLAG_Q_TOKEN_MAJOR) ? 1 : 0, ln_eps};
     hipLaunchKernelGGL(ob_qkv_rope_kernel, dim3((unsigned)(B * S)), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
     return ob_launch_status("rows_qkv_rope");
 }
@@ -878,7 +902,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
         if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
-        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps};
+        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr};
         hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges

@@ -18,6 +18,7 @@ in ``onebit_amd/engine.py``.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -249,45 +250,65 @@ class OneBitLlamaForCausalLM(nn.Module):
         cos, sin = self._rope_tables(h.device, h.dtype)
         sp = _stream_ptr(h.device)
 
-        def res_ln_rms(hres, u, w):
-            hout, x = torch.empty_like(hres), torch.empty_like(hres)
+        def res_ln_rms(hres, u, w, consumers=()):
+            """hres + LayerNorm(u) -> new residual; RMSNorm -> x.  ``consumers``: projections that read x; when all of
+            them take pre-scaled rows at this T the kernel writes fp16(x * h_i) for each instead of x and they run
+            with ONEBIT_FLAG_PRESCALED (no separate scaling pass).  Returns (residual, x or None, [a_i] or None)."""
+            hout = torch.empty_like(hres)
+            pres = bool(consumers) and all(p.prescaled_ok(T, hres.dtype) for p in consumers)
+            x = None if pres else torch.empty_like(hres)
+            xs = [torch.empty_like(hres) for _ in consumers] if pres else []
+            hp = (ctypes.c_void_p * 3)(*[p.input_factor.data_ptr() for p in consumers][:len(xs)])
+            xp = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in xs])
             with torch.cuda.device(h.device):
-                _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(), x.data_ptr(),
+                _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(),
+                                                      None if x is None else x.data_ptr(), hp, xp, len(xs),
                                                       T, H, cfg.rms_norm_eps, 1e-5, sp), "onebit_rows_res_ln_rms")
-            return hout, x
+            return hout, x, (xs if pres else None)
 
-        x = m.layers[0].input_layernorm(h)
+        def proj(p, x, a):
+            return p.pre_layernorm_prescaled(a) if a is not None else p.pre_layernorm(x)
+
+        x, xs = m.layers[0].input_layernorm(h), None
         u_down = None
         for li, (layer, kv) in enumerate(zip(m.layers, cache.layers)):
-            if u_down is not None:
-                h, x = res_ln_rms(h, u_down, layer.input_layernorm.weight)
             att = layer.self_attn
-            if (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
-                    and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()):
+            fused_attn = (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
+                          and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous())
+            if u_down is not None:
+                h, x, xs = res_ln_rms(h, u_down, layer.input_layernorm.weight,
+                                      (att.q_proj, att.k_proj, att.v_proj) if fused_attn else ())
+            if fused_attn:
                 # q|k|v LayerNorm + RoPE + head transpose in one pass (onebit_rows_qkv_rope): k, v land in
-                # the cache rows, q in [B, heads, S, D]; then the fused causal attention
+                # the cache rows, q in token-major [B, S, heads, D]; then the fused causal attention
                 Hh, Hkv, D = att.num_heads, att.num_key_value_heads, att.head_dim
-                u_q, u_k, u_v = att.q_proj.pre_layernorm(x), att.k_proj.pre_layernorm(x), att.v_proj.pre_layernorm(x)
-                q = torch.empty((B, Hh, S, D), dtype=x.dtype, device=x.device)
+                aq, ak, av = xs if xs is not None else (None, None, None)
+                u_q, u_k, u_v = proj(att.q_proj, x, aq), proj(att.k_proj, x, ak), proj(att.v_proj, x, av)
+                q = torch.empty((B, S, Hh, D), dtype=h.dtype, device=h.device)     # token-major: sdpa returns the same layout
                 kc, vc = kv
                 with torch.cuda.device(h.device):
                     _lib.check(lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                                         q.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past,
-                                                        kc.shape[2], cos.shape[0], 1e-5, sp), "onebit_rows_qkv_rope")
+                                                        kc.shape[2], cos.shape[0], 1e-5, _lib.FLAG_Q_TOKEN_MAJOR, sp), "onebit_rows_qkv_rope")
                 keys, vals = kc[:B, :, :S], vc[:B, :, :S]
                 if Hkv != Hh:
                     keys, vals = keys.repeat_interleave(Hh // Hkv, dim=1), vals.repeat_interleave(Hh // Hkv, dim=1)
-                o = nn.functional.scaled_dot_product_attention(q, keys, vals, is_causal=True)
-                u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))
+                o = nn.functional.scaled_dot_product_attention(q.transpose(1, 2), keys, vals, is_causal=True)
+                u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))    # (no copy when o is token-major)
             else:
                 u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
-            h, x = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight)
-            u_g, u_u = layer.mlp.gate_proj.pre_layernorm(x), layer.mlp.up_proj.pre_layernorm(x)
+            mlp = layer.mlp
+            h, x, xs = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight, (mlp.gate_proj, mlp.up_proj))
+            ag, au = xs if xs is not None else (None, None)
+            u_g, u_u = proj(mlp.gate_proj, x, ag), proj(mlp.up_proj, x, au)
             act = torch.empty_like(u_g)
+            down_pres = mlp.down_proj.prescaled_ok(T, h.dtype)
             with torch.cuda.device(h.device):
-                _lib.check(lib.onebit_rows_swiglu(u_g.data_ptr(), u_u.data_ptr(), act.data_ptr(), T, I, 1e-5, sp), "onebit_rows_swiglu")
-            u_down = layer.mlp.down_proj.pre_layernorm(act)
-        h, x = res_ln_rms(h, u_down, m.norm.weight)
+                _lib.check(lib.onebit_rows_swiglu(u_g.data_ptr(), u_u.data_ptr(),
+                                                  mlp.down_proj.input_factor.data_ptr() if down_pres else None,
+                                                  act.data_ptr(), T, I, 1e-5, sp), "onebit_rows_swiglu")
+            u_down = mlp.down_proj.pre_layernorm_prescaled(act) if down_pres else mlp.down_proj.pre_layernorm(act)
+        h, x, _ = res_ln_rms(h, u_down, m.norm.weight)
         return self.lm_head(x.view(B, S, H)).float()
 
     @torch.no_grad()

@@ -267,3 +267,52 @@ def test_k_sharded_prefill_full_size_vs_oracle(coracle):
         _check_u(un[i], u_ref[i], "row %d" % r)
         rel = np.linalg.norm(yn[i].astype(np.float32) - y_ref[i].astype(np.float32)) / np.linalg.norm(y_ref[i].astype(np.float32))
         assert rel <= 1e-3, (r, rel)
+
+
+def test_prescaled_route_is_bit_identical_at_full_size():
+    """ONEBIT_FLAG_PRESCALED (BASELINE config 3 shape, T = 16384): the producer kernels write fp16(x * h) themselves
+    (onebit_rows_res_ln_rms with h_next, onebit_rows_swiglu with h_next) and the projection skips its scaling pass --
+    the same kernel on the same rows, so the pre-LayerNorm output must equal the ordinary call's bit for bit; the
+    flag is refused on a shape that does not take the LDS-DMA GEMM."""
+    import ctypes
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    K, N, T = 4096, 11008, 8 * 2048
+    m, packed, h, g = _mk(K, N, 41, dev)
+    assert m.prescaled_ok(T)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    hres = torch.randn(T, K, generator=gen).half().to(dev)
+    u_prev = (0.3 * torch.randn(T, K, generator=gen)).half().to(dev)
+    w = (1.0 + 0.1 * torch.randn(K, generator=gen)).half().to(dev)
+    sp = _stream_ptr(dev)
+    # ordinary: x, then the projection scales it itself
+    hout, x = torch.empty_like(hres), torch.empty_like(hres)
+    nul = (ctypes.c_void_p * 3)()
+    _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u_prev.data_ptr(), w.data_ptr(), hout.data_ptr(), x.data_ptr(),
+                                          nul, nul, 0, T, K, 1e-6, 1e-5, sp), "rows_res_ln_rms")
+    u_ref = m.pre_layernorm(x)
+    # fused: the norm kernel writes fp16(x * h) (and x as well here, to compare)
+    hout2, x2, a = torch.empty_like(hres), torch.empty_like(hres), torch.empty_like(hres)
+    hp = (ctypes.c_void_p * 3)(m.input_factor.data_ptr())
+    xp = (ctypes.c_void_p * 3)(a.data_ptr())
+    _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u_prev.data_ptr(), w.data_ptr(), hout2.data_ptr(), x2.data_ptr(),
+                                          hp, xp, 1, T, K, 1e-6, 1e-5, sp), "rows_res_ln_rms")
+    assert torch.equal(x2, x) and torch.equal(hout2, hout)
+    assert torch.equal(a, x * m.input_factor.data)                  # fp16 product, rounded once (bitnet.py:113)
+    assert torch.equal(m.pre_layernorm_prescaled(a), u_ref)
+    # swiglu with h_next: act * h, rounded once more
+    I = 11008
+    ug = (0.5 * torch.randn(2048, I, generator=gen)).half().to(dev)
+    uu = (0.5 * torch.randn(2048, I, generator=gen)).half().to(dev)
+    hd = (0.1 * (0.5 + torch.rand(I, generator=gen))).half().to(dev)
+    act, act_s = torch.empty_like(ug), torch.empty_like(ug)
+    _lib.check(lib.onebit_rows_swiglu(ug.data_ptr(), uu.data_ptr(), None, act.data_ptr(), 2048, I, 1e-5, sp), "rows_swiglu")
+    _lib.check(lib.onebit_rows_swiglu(ug.data_ptr(), uu.data_ptr(), hd.data_ptr(), act_s.data_ptr(), 2048, I, 1e-5, sp), "rows_swiglu")
+    assert torch.equal(act_s, act * hd)
+    # a shape on another kernel route refuses the flag
+    small, *_ = _mk(512, 64, 5, dev)
+    assert not small.prescaled_ok(8)
+    with pytest.raises(Exception):
+        small.pre_layernorm_prescaled(torch.zeros(8, 512, dtype=torch.float16, device=dev))

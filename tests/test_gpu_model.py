@@ -168,8 +168,13 @@ def test_rows_qkv_rope_matches_module_ops():
     kc = torch.zeros(B + 1, Hkv, max_len, D, dtype=torch.float16, device=dev)
     vc = torch.zeros_like(kc)
     rc = lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(),
-                                  kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past, max_len, max_pos, 1e-5, _stream_ptr(dev))
+                                  kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past, max_len, max_pos, 1e-5, 0, _stream_ptr(dev))
     _lib.check(rc, "rows_qkv_rope")
+    q_tm = torch.zeros(B, S, Hh, D, dtype=torch.float16, device=dev)        # ONEBIT_FLAG_Q_TOKEN_MAJOR: same values, [B, S, H, D]
+    rc = lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(), q_tm.data_ptr(),
+                                  kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past, max_len, max_pos, 1e-5, 0x2, _stream_ptr(dev))
+    _lib.check(rc, "rows_qkv_rope")
+    assert torch.equal(q_tm.transpose(1, 2), q)
 
     def rot(x):
         return torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1)
@@ -189,7 +194,7 @@ def test_rows_qkv_rope_matches_module_ops():
     assert float(kc[B].abs().max()) == 0 and float(kc[:, :, :past].abs().max()) == 0 and float(kc[:, :, past + S:].abs().max()) == 0
     # error behaviour: tokens beyond the cache
     assert lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(), q.data_ptr(),
-                                    kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, 30, max_len, max_pos, 1e-5, _stream_ptr(dev)) != 0
+                                    kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, 30, max_len, max_pos, 1e-5, 0, _stream_ptr(dev)) != 0
 
 
 @pytest.mark.parametrize("name", ["a", "b"])
@@ -214,3 +219,14 @@ def test_fused_glue_with_sdpa_uses_rows_qkv_rope_within_tolerance(golden_dir, na
     lg2 = model(torch.tensor([[int(toks[0]), int(toks[1])]], device=dev), cache).cpu().numpy()
     assert np.abs(lg2[0, 0] - z["decode_logits_f16"][0][0]).max() <= tol
     assert np.abs(lg2[0, 1] - z["decode_logits_f16"][0][1]).max() <= tol
+
+
+def test_prescaled_prefill_route_forced_on_a_small_model():
+    """The fused forward's pre-scaled route (producers write fp16(x * h), projections run with
+    ONEBIT_FLAG_PRESCALED) only opens where the LDS-DMA GEMM is eligible; OB_GEMM3=2 forces that on a small
+    model in a child interpreter, which compares the route with the module path's logits."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_prescaled_child.py")
+    r = subprocess.run([sys.executable, child], env=dict(os.environ, OB_GEMM3="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced-prescaled ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
