@@ -430,6 +430,36 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
 #undef OB_G3_MMA
 #undef OB_G3_READ
 
+    // Epilogue through LDS (fp16 outputs, wave's 64 rows inside N): a lane's accumulators are 4 consecutive rows
+    // of one token -- stored directly that is 8 bytes per lane and 32 contiguous bytes per token row and instruction.
+    // Each wave transposes its 64 x 128 tile in its own 18 KB of the (now idle: every read finished before the
+    // last barrier) staging memory and writes whole 128-byte row segments, 8 token rows per instruction.
+    if (!PARTIAL && n0 + wn * 64 + 64 <= N && (N & 7) == 0 && (reinterpret_cast<size_t>(u) & 15) == 0 && !(OB_G3_ABL & 32)) {
+        constexpr int EP = 144;                                // bytes per token row: 128 + 16 (rows shift by 4 banks)
+        char *ep = smem + (size_t)wave * 128 * EP;
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) {
+            const int nb = n0 + wn * 64 + rn * 16 + 4 * gq;
+            const ob_half4 g4 = *reinterpret_cast<const ob_half4 *>(g + nb);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                ob_half4 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (_Float16)(ob_round_h(acc[rn][rt][i]) * (float)g4[i]);   // fp16(z) (:115), * g -> fp16 (:116)
+                *reinterpret_cast<ob_half4 *>(ep + (rt * 16 + r) * EP + (rn * 16 + 4 * gq) * 2) = ov;
+            }
+        }
+        // (same wave wrote what it reads: no barrier, the compiler orders the LDS accesses with lgkmcnt)
+        _Float16 *ub = u + (int64_t)(t0 + wt * 128) * N + n0 + wn * 64;
+        const int trows = T - (t0 + wt * 128);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = j * 8 + (lane >> 3), ch = lane & 7;
+            const ob_half8 v = *reinterpret_cast<const ob_half8 *>(ep + row * EP + ch * 16);
+            if (row < trows) *reinterpret_cast<ob_half8 *>(ub + (int64_t)row * N + ch * 8) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) {
         const int nb = n0 + wn * 64 + rn * 16 + 4 * gq;
