@@ -41,3 +41,45 @@ def test_scheduler_token_budget_is_fifo_and_validates():
         s.add([1] * 40, 1)
     with pytest.raises(ValueError):
         s.add([1] * 7, 1)
+
+
+def test_scheduler_chunked_prefill_plans_and_first_token():
+    """prefill_chunk: a prompt enters at most that many tokens per step, running requests keep decoding in the
+    same steps, and a request produces its first token only with its last chunk."""
+    s = Scheduler(max_batch=2, max_len=32, prefill_chunk=3)
+    a = s.add([1, 2, 3, 4, 5, 6, 7], 2)             # 3 chunks: 3 + 3 + 1
+    b = s.add([9], 3)
+    p1 = s.plan()
+    assert [(it.req.rid, it.tokens, it.start) for it in p1] == [(a, [1, 2, 3], 0), (b, [9], 0)]
+    assert s.commit(p1, [100, 20]) == []            # a's logits are dropped: its prompt is still entering
+    assert s.running[0].out == [] and s.running[0].pos == 3
+    p2 = s.plan()                                   # b decodes first, a's next chunk behind it
+    assert [(it.req.rid, it.tokens, it.start) for it in p2] == [(b, [20], 1), (a, [4, 5, 6], 3)]
+    s.commit(p2, [21, 101])
+    p3 = s.plan()
+    assert [(it.req.rid, it.tokens, it.start) for it in p3] == [(b, [21], 2), (a, [7], 6)]
+    done = s.commit(p3, [22, 30])                   # a's last chunk: first token sampled; b finishes
+    assert [r.rid for r in done] == [b] and s.finished[b].out == [20, 21, 22]
+    p4 = s.plan()
+    assert [(it.req.rid, it.tokens, it.start) for it in p4] == [(a, [30], 7)]
+    done = s.commit(p4, [31])
+    assert [r.rid for r in done] == [a] and s.finished[a].out == [30, 31] and s.idle
+
+
+def test_scheduler_chunked_prefill_with_token_budget():
+    """With a step budget the chunk shrinks to what is left, long prompts are accepted, FIFO order holds."""
+    s = Scheduler(max_batch=3, max_len=64, max_step_tokens=5, prefill_chunk=4)
+    a = s.add(list(range(10)), 1)                   # longer than the budget: fine when chunked
+    b = s.add([7, 8, 9], 1)
+    p = s.plan()                                    # 4 tokens of a, then 1 of b (budget 5)
+    assert [(it.req.rid, len(it.tokens), it.start) for it in p] == [(a, 4, 0), (b, 1, 0)]
+    s.commit(p, [0, 0])
+    p = s.plan()
+    assert [(it.req.rid, len(it.tokens), it.start) for it in p] == [(a, 4, 4), (b, 1, 1)]
+    s.commit(p, [0, 0])
+    p = s.plan()                                    # a: last 2 tokens; b: its last token
+    assert [(it.req.rid, len(it.tokens), it.start) for it in p] == [(a, 2, 8), (b, 1, 2)]
+    done = s.commit(p, [41, 42])
+    assert sorted(r.rid for r in done) == [a, b] and s.finished[a].out == [41] and s.finished[b].out == [42]
+    with pytest.raises(ValueError):
+        Scheduler(2, 8, prefill_chunk=0)
