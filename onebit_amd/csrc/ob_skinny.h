@@ -39,16 +39,29 @@ struct ObSkinnyArgs {
     ObSkinnyProj p[3];
     long long ldx;
     int T;
+    unsigned long long *dbg;      // -DOB_PROFILE_STAMPS builds: 16 cycle stamps per wave (tools/skinny_phase_probe.py)
 };
 
 // tokens x k elements of one phase: 16*RT x 512 (42 / 75 / 142 KB of LDS with the packed rows: three,
 // two or one workgroup per CU)
 #define OB_SKINNY_PKT(RT_) (512 * (RT_))
 #define OB_SKINNY_LDS(RT_) ((size_t)2 * 16 * (RT_) * (512 + 8) * 2 + (size_t)2 * 64 * (512 / 32 + 1) * 4)
+// RNT = 16-row tiles per workgroup: 4 (64 rows), or 8 (128 rows) for the wide layers of the batched step --
+// what these launches move is the [T, K] activation block, once per workgroup out of L2 (the slope of the
+// T = 16 / 32 / 64 timings: ~7 TB/s chip-wide); twice the rows per workgroup is half of that traffic.
+#define OB_SKINNY_LDS2(RT_, RNT_) ((size_t)2 * 16 * (RT_) * (512 + 8) * 2 + (size_t)2 * 16 * (RNT_) * (512 / 32 + 1) * 4)
 
-template <bool PARTIAL, int RT>
+template <bool PARTIAL, int RT, int RNT = 4>
 __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A)
 {
+    constexpr int ROWS = 16 * RNT;
+#ifdef OB_PROFILE_STAMPS
+    unsigned long long stamp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define OB_SK_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp_[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define OB_SK_STAMP(i) do { } while (0)
+#endif
+    OB_SK_STAMP(0);
     const int pi = (int)blockIdx.x < A.p[0].tile_end ? 0 : ((int)blockIdx.x < A.p[1].tile_end ? 1 : 2);
     const ObSkinnyProj P = pi == 0 ? A.p[0] : (pi == 1 ? A.p[1] : A.p[2]);
     const uint32_t *__restrict__ W = P.W;
@@ -68,11 +81,11 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     constexpr int WPR = PK / 128;               // 16-byte packed pieces per weight row and phase
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16 *As = reinterpret_cast<_Float16 *>(smem);                                   // [2][TT][PITCH]
-    uint32_t *Ws = reinterpret_cast<uint32_t *>(smem + (size_t)2 * TT * PITCH * 2);      // [2][64][WP]
+    uint32_t *Ws = reinterpret_cast<uint32_t *>(smem + (size_t)2 * TT * PITCH * 2);      // [2][ROWS][WP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, gq = lane >> 4;
     const int wq = wave >> 1, hf = wave & 1;    // this wave's packed word and half of every chunk
-    const int n0 = ((int)blockIdx.x - tile0) * 64;
+    const int n0 = ((int)blockIdx.x - tile0) * ROWS;
     const int nph = (K + PK - 1) / PK;
     const int nwords = K >> 5;
 
@@ -84,13 +97,13 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
     const _Float16 *xrow[NSTG];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) xrow[i] = x + (int64_t)min(tok0 + TSTEP * i, T - 1) * ldx;
-    const bool wload = tid < 64 * WPR;
+    const bool wload = tid < ROWS * WPR;
     const int wrow_i = wload ? tid / WPR : 0, wpc = wload ? tid % WPR : 0;
     const uint32_t *wsrc = W + (int64_t)min(n0 + wrow_i, N - 1) * ldw_words;
 
-    ob_float4 acc[4][RT];
+    ob_float4 acc[RNT][RT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RNT; ++a)
 #pragma unroll
         for (int b = 0; b < RT; ++b) acc[a][b] = (ob_float4){0.f, 0.f, 0.f, 0.f};
 
@@ -118,28 +131,34 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
             *reinterpret_cast<ob_half8 *>(dst + (size_t)(tok0 + TSTEP * i) * PITCH) = a;
         }
         if (wload) {
-            uint32_t *wd = Ws + ((size_t)buf * 64 + wrow_i) * WP + wpc * 4;
+            uint32_t *wd = Ws + ((size_t)buf * ROWS + wrow_i) * WP + wpc * 4;
             const ob_u32x4 w = wv_ld ? wv : (ob_u32x4){0u, 0u, 0u, 0u};
             wd[0] = w[0]; wd[1] = w[1]; wd[2] = w[2]; wd[3] = w[3];                    // WP is odd: dword stores
         }
     };
 
+    // The loads of phase ph + 1 are issued BEFORE the barrier that ends phase ph - 1 (right behind the LDS stores
+    // that emptied the staging registers): a workgroup is alone on its CU for most layer shapes, and issued at the
+    // top of phase ph they had only its ~1500 cycles of MFMA work to cover ~1900 cycles of latency -- every phase
+    // then ended parked on them (tools/skinny_phase_probe.py: 2500 cycles per phase).
     load_phase(0);
+    OB_SK_STAMP(1);
     store_phase(0);
+    if (nph > 1) load_phase(1);
     __syncthreads();
+    OB_SK_STAMP(2);
 
     for (int ph = 0; ph < nph; ++ph) {
         const int cur = ph & 1;
         const bool more = ph + 1 < nph;
-        if (more) load_phase(ph + 1);
         __builtin_amdgcn_sched_barrier(0);
         const _Float16 *Ab = As + (size_t)cur * TT * PITCH + (size_t)r * PITCH + gq * 128 + wq * 32 + hf * 16;
-        const uint32_t *Wb = Ws + ((size_t)cur * 64 + r) * WP + gq * 4 + wq;
+        const uint32_t *Wb = Ws + ((size_t)cur * ROWS + r) * WP + gq * 4 + wq;
 #pragma unroll
         for (int c = 0; c < CPP; ++c) {
-            uint32_t e[4][8];
+            uint32_t e[RNT][8];
 #pragma unroll
-            for (int rn = 0; rn < 4; ++rn)
+            for (int rn = 0; rn < RNT; ++rn)
                 ob_expand16((Wb[(size_t)rn * 16 * WP + c * 16] >> (16 * hf)) & 0xffffu, e[rn]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
                 for (int rt = 0; rt < RT; ++rt)
                     bop[rt] = *reinterpret_cast<const ob_half8 *>(Ab + (size_t)rt * 16 * PITCH + c * 512 + s2 * 8);
 #pragma unroll
-                for (int rn = 0; rn < 4; ++rn) {
+                for (int rn = 0; rn < RNT; ++rn) {
                     ob_u32x4 av = {e[rn][4 * s2 + 0], e[rn][4 * s2 + 1], e[rn][4 * s2 + 2], e[rn][4 * s2 + 3]};
                     ob_half8 aop;
                     __builtin_memcpy(&aop, &av, 16);
@@ -159,72 +178,92 @@ __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) OB_SK_STAMP(3);                        // MFMAs of phase 0 issued
         if (more) store_phase(cur ^ 1);
+        if (ph + 2 < nph) load_phase(ph + 2);
         __syncthreads();
+        if (ph == 0) OB_SK_STAMP(4);
+        if (ph == 1) OB_SK_STAMP(5);
+        if (ph == 3) OB_SK_STAMP(6);
     }
+    OB_SK_STAMP(7);
 
-    // the 8 waves' partial accumulators meet in LDS (the staging buffers are free after the last barrier):
-    // [wave][rn][rt][lane] float4, then output slot (rn, rt, lane) is summed by one thread
+    // the 8 waves' partial accumulators meet in LDS (the staging buffers are free after the last barrier),
+    // four row tiles per pass: [wave][rn][rt][lane] float4, then output slot (rn, rt, lane) is summed by one thread
     ob_float4 *zr = reinterpret_cast<ob_float4 *>(smem);
-#pragma unroll
-    for (int rn = 0; rn < 4; ++rn)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) zr[((wave * 4 + rn) * RT + rt) * 64 + lane] = acc[rn][rt];
-    __syncthreads();
     constexpr int NSLOT = 4 * RT * 64;
-    for (int slot = tid; slot < NSLOT; slot += 512) {
-        const int sl = slot & 63, rt = (slot >> 6) % RT, rn = (slot >> 6) / RT;
-        ob_float4 z = zr[((0 * 4 + rn) * RT + rt) * 64 + sl];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) z += zr[((w * 4 + rn) * RT + rt) * 64 + sl];
-        const int t = rt * 16 + (sl & 15);
-        const int nb = n0 + rn * 16 + 4 * (sl >> 4);
-        if (!PARTIAL && stp) {
-            // the consumer's LayerNorm partials: the 16 rows of tile rn for token t live in the lanes
-            // sl, sl ^ 16, sl ^ 32, sl ^ 48 (4 rows each); every lane of the wave is here (uniform trip count)
-            float o4[4], sm = 0.f;
+    for (int pass = 0; pass < RNT / 4; ++pass) {
+        if (pass) __syncthreads();                          // the previous pass's sums have been read
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o4[i] = (float)(_Float16)(ob_round_h(z[i]) * (float)g[min(nb + i, N - 1)]);
-                sm += o4[i];
+        for (int rn = 0; rn < 4; ++rn)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) zr[((wave * 4 + rn) * RT + rt) * 64 + lane] = acc[4 * pass + rn][rt];
+        __syncthreads();
+        if (pass == 0) OB_SK_STAMP(8);
+        for (int slot = tid; slot < NSLOT; slot += 512) {
+            const int sl = slot & 63, rt = (slot >> 6) % RT, rn = (slot >> 6) / RT;
+            ob_float4 z = zr[((0 * 4 + rn) * RT + rt) * 64 + sl];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) z += zr[((w * 4 + rn) * RT + rt) * 64 + sl];
+            const int t = rt * 16 + (sl & 15);
+            const int ntile = n0 + (4 * pass + rn) * 16;
+            const int nb = ntile + 4 * (sl >> 4);
+            if (!PARTIAL && stp) {
+                // the consumer's LayerNorm partials: the 16 rows of the tile for token t live in the lanes
+                // sl, sl ^ 16, sl ^ 32, sl ^ 48 (4 rows each); every lane of the wave is here (uniform trip count)
+                float o4[4], sm = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o4[i] = (float)(_Float16)(ob_round_h(z[i]) * (float)g[min(nb + i, N - 1)]);
+                    sm += o4[i];
+                }
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                const float mu = sm * 0.0625f;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m2 = __builtin_fmaf(o4[i] - mu, o4[i] - mu, m2);
+                m2 += __shfl_xor(m2, 16);
+                m2 += __shfl_xor(m2, 32);
+                if (sl < 16 && t < T && ntile < N) {
+                    float *d = stp + (size_t)t * ob_tile_stats_floats(N) + (size_t)(ntile >> 4) * 2;
+                    d[0] = sm; d[1] = m2;
+                }
             }
-            sm += __shfl_xor(sm, 16);
-            sm += __shfl_xor(sm, 32);
-            const float mu = sm * 0.0625f;
-            float m2 = 0.f;
+            if (t >= T) continue;
+            if (PARTIAL) {
+                if (nb + 3 < N && (N & 3) == 0) {
+                    *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = z;
+                } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m2 = __builtin_fmaf(o4[i] - mu, o4[i] - mu, m2);
-            m2 += __shfl_xor(m2, 16);
-            m2 += __shfl_xor(m2, 32);
-            if (sl < 16 && t < T && n0 + rn * 16 < N) {
-                float *d = stp + (size_t)t * ob_tile_stats_floats(N) + (size_t)((n0 >> 4) + rn) * 2;
-                d[0] = sm; d[1] = m2;
-            }
-        }
-        if (t >= T) continue;
-        if (PARTIAL) {
-            if (nb + 3 < N && (N & 3) == 0) {
-                *reinterpret_cast<ob_float4 *>(zp + (int64_t)t * N + nb) = z;
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < N) zp[(int64_t)t * N + nb + i] = z[i];
+                }
             } else {
+                _Float16 o[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (nb + i < N) zp[(int64_t)t * N + nb + i] = z[i];
-            }
-        } else {
-            _Float16 o[4];
+                for (int i = 0; i < 4; ++i) {
+                    const float gn = (float)g[min(nb + i, N - 1)];
+                    o[i] = (_Float16)(ob_round_h(z[i]) * gn);                  // fp16(z) (:115), * g -> fp16 (:116)
+                }
+                if (nb + 3 < N && (N & 3) == 0) {
+                    ob_half4 ov = {o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<ob_half4 *>(u + (int64_t)t * N + nb) = ov;
+                } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float gn = (float)g[min(nb + i, N - 1)];
-                o[i] = (_Float16)(ob_round_h(z[i]) * gn);                  // fp16(z) (:115), * g -> fp16 (:116)
-            }
-            if (nb + 3 < N && (N & 3) == 0) {
-                ob_half4 ov = {o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<ob_half4 *>(u + (int64_t)t * N + nb) = ov;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (nb + i < N) u[(int64_t)t * N + nb + i] = o[i];
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < N) u[(int64_t)t * N + nb + i] = o[i];
+                }
             }
         }
     }
+#ifdef OB_PROFILE_STAMPS
+    OB_SK_STAMP(9);
+    if (A.dbg && (threadIdx.x & 63) == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i_ = 0; i_ < 16; ++i_) A.dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + i_] = stamp_[i_];
+    }
+#endif
+#undef OB_SK_STAMP
 }

@@ -139,13 +139,27 @@ static void ob_launch_simple(const void *packed, int64_t ldw_bytes, const void *
 static int ob_cu_count();
 static inline size_t ob_skinny_lds(int rt) { return OB_SKINNY_LDS(rt); }
 
-template <bool PARTIAL, int RT>
-static void ob_launch_skinny(const ObSkinnyArgs &ka, int tiles, hipStream_t s)
+#ifdef OB_PROFILE_STAMPS
+static unsigned long long *g_dbg = nullptr;
+static unsigned long long *ob_dbg_buffer()
 {
-    const size_t lds = ob_skinny_lds(RT);
+    if (!getenv("OB_TIMING")) return nullptr;
+    if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 128 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 128 * sizeof(unsigned long long)); }
+    return g_dbg;
+}
+#endif
+
+template <bool PARTIAL, int RT, int RNT = 4>
+static void ob_launch_skinny(const ObSkinnyArgs &ka_in, int tiles, hipStream_t s)
+{
+    ObSkinnyArgs ka = ka_in;
+#ifdef OB_PROFILE_STAMPS
+    ka.dbg = ob_dbg_buffer();
+#endif
+    const size_t lds = OB_SKINNY_LDS2(RT, RNT) > (size_t)RT * 32768 ? OB_SKINNY_LDS2(RT, RNT) : (size_t)RT * 32768;
     static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_skinny_f16_kernel<PARTIAL, RT>, attr_set, (int)lds);
-    hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT>), dim3((unsigned)tiles), dim3(512), lds, s, ka);
+    ob_set_max_lds_once(ob_skinny_f16_kernel<PARTIAL, RT, RNT>, attr_set, (int)lds);
+    hipLaunchKernelGGL((ob_skinny_f16_kernel<PARTIAL, RT, RNT>), dim3((unsigned)tiles), dim3(512), lds, s, ka);
 }
 
 static inline bool ob_skinny_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K)
@@ -248,7 +262,10 @@ static bool ob_gemm3_ok(int64_t T, int64_t K, int64_t N)
     // whole quads of K steps; 32-bit byte offsets from the base pointers inside the kernel
     if (!env || T < 192 || K % (4 * OB_G2_K) != 0 || N % 4 != 0 || T * K * 2 >= ((int64_t)1 << 32) || N * (K / 8) >= ((int64_t)1 << 32)) return false;
     const int64_t tiles = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + OB_G2_T - 1) / OB_G2_T);
-    return tiles >= 4 * (int64_t)ob_cu_count() || env == 2;
+    // from ~4 rounds of tiles always; below that when the last round is at least two thirds full
+    // ([2048, 4096] -> 11008: 344 tiles on 256 CUs, 974 vs 903 TFLOP/s for the 128 x 128 kernel; 43 tiles: 258 vs 446)
+    const int64_t cu = ob_cu_count(), rounds = (tiles + cu - 1) / cu;
+    return tiles >= 4 * cu || (tiles >= cu && 3 * tiles >= 2 * rounds * cu) || env == 2;
 }
 
 // bytes a call cannot do without (F32: fp32 z is staged in y itself; F16 on the MFMA path: u is staged in
@@ -585,7 +602,6 @@ static int ob_ablate_mode()
 }
 
 #ifdef OB_PROFILE_STAMPS
-static unsigned long long *g_dbg = nullptr;
 extern "C" int onebit_debug_read_timing(unsigned long long *host_out, int nblocks)
 {
     if (!g_dbg) return -1;
@@ -599,10 +615,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     ObGemvArgs a = a_in;
     a.ablate = ob_ablate_mode();
 #ifdef OB_PROFILE_STAMPS
-    if (getenv("OB_TIMING")) {
-        if (!g_dbg) { (void)hipMalloc(&g_dbg, 4096 * 128 * sizeof(unsigned long long)); (void)hipMemset(g_dbg, 0, 4096 * 128 * sizeof(unsigned long long)); }
-        a.dbg = g_dbg;
-    }
+    a.dbg = ob_dbg_buffer();
 #endif
     int max_tiles = 0;
     for (int p = 0; p < a.nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
@@ -834,23 +847,57 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             }
             return ob_launch_status("decode_step_batched(gemm)");
         }
+        // OB_SKINNY_WIDE=1: 128-row workgroups for the wide launches (q|k|v, gate|up) -- half the activation
+        // traffic out of L2, half the workgroups.  Measured SLOWER (32-slot 7B step 2.85 vs 2.75 ms): off.
+        int64_t nsum = 0;
+        for (int i = 0; i < np; ++i) nsum += ps.p[i]->N;
+        static const int wide_env = getenv("OB_SKINNY_WIDE") ? atoi(getenv("OB_SKINNY_WIDE")) : 0;
+        const bool wide = wide_env && nsum >= 96 * 128 && B <= 32;
+        const int rows = wide ? 128 : 64;
         ObSkinnyArgs ka = {};
         int tiles = 0;
         for (int i = 0; i < 3; ++i) {
             const int j = i < np ? i : np - 1;
             const onebit_proj_t &p = *ps.p[j];
-            if (i < np) tiles += (int)((p.N + 63) / 64);
+            if (i < np) tiles += (int)((p.N + rows - 1) / rows);
             ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.input_factor,
                        (const _Float16 *)p.weight_scale, (const _Float16 *)xin, (_Float16 *)us.u[j], nullptr, (int)p.N,
                        (int)K, tiles, ss.s[j]};
         }
         stats_written = ss.s[0] != nullptr;
         ka.ldx = K; ka.T = B;
-        if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
+        if (wide && B <= 16) ob_launch_skinny<false, 1, 8>(ka, tiles, s);
+        else if (wide) ob_launch_skinny<false, 2, 8>(ka, tiles, s);
+        else if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
         else if (B <= 32) ob_launch_skinny<false, 2>(ka, tiles, s);
         else ob_launch_skinny<false, 4>(ka, tiles, s);
         return ob_launch_status("decode_step_batched(gemm)");
     };
+    // Short-and-wide projections (N = hidden: o, down) have 64 row tiles for 256 CUs: split K over two
+    // workgroup ranges, fp32 partial sums into two free [B, H] scratch rows, summed by the next norm kernel
+    auto gemm_splitk2 = [&](const onebit_proj_t &p, const void *xin, int64_t K, float *z0, float *z1, const char *name) -> int {
+        if (!p.weight || !p.input_factor || !p.weight_scale || p.K != K || p.N != H || p.ldw_bytes % 16 != 0)
+            return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: projection %s has an unexpected shape", name);
+        const int Kh = (int)(K / 2), tiles1 = (H + 63) / 64;
+        ObSkinnyArgs ka = {};
+        for (int i = 0; i < 3; ++i) {
+            const int j = i < 2 ? i : 1;
+            ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4),
+                       (const _Float16 *)p.input_factor + j * Kh, (const _Float16 *)p.weight_scale,
+                       (const _Float16 *)xin + j * Kh, nullptr, j == 0 ? z0 : z1, H, Kh, tiles1 * (j + 1)};
+        }
+        ka.ldx = K; ka.T = B;
+        if (B <= 16) ob_launch_skinny<true, 1>(ka, 2 * tiles1, s);
+        else if (B <= 32) ob_launch_skinny<true, 2>(ka, 2 * tiles1, s);
+        else ob_launch_skinny<true, 4>(ka, 2 * tiles1, s);
+        return ob_launch_status("decode_step_batched(split-K gemm)");
+    };
+    // o_proj: K = hidden halves; its partial sums use the u_gate / u_up rows as well (free until gate|up runs)
+    bool splitk_o = splitk_env && H % 256 == 0 && (int64_t)I * 2 >= (int64_t)H * 4 && NQ == H;
+    for (int l = 0; splitk_o && l < m->n_layers; ++l)
+        splitk_o = m->layers[l].o.weight && m->layers[l].o.ldw_bytes % 16 == 0 &&
+                   ob_skinny_ok((const uint32_t *)m->layers[l].o.weight + (H / 2) / 32, m->layers[l].o.ldw_bytes, B, H / 2) &&
+                   ob_skinny_ok(m->layers[l].o.weight, m->layers[l].o.ldw_bytes, B, H / 2);
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -893,11 +940,13 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
+        if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
+        else if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
         // 5. residual + LayerNorm(u_o) + post-attention RMSNorm
         ObBNormArgs nb = na;
         nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
-        nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o; nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
+        nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
+        if (splitk_o) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; } nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
         hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
@@ -908,22 +957,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges
         //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
         if (splitk_down) {
-            const onebit_proj_t &p = L.down;
-            if (!p.weight || !p.input_factor || !p.weight_scale || p.K != I || p.N != H || p.ldw_bytes % 16 != 0)
-                return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: projection down has an unexpected shape");
-            const int Kh = I / 2, tiles1 = (H + 63) / 64;
-            ObSkinnyArgs ka = {};
-            for (int i = 0; i < 3; ++i) {
-                const int j = i < 2 ? i : 1;
-                ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4),
-                           (const _Float16 *)p.input_factor + j * Kh, (const _Float16 *)p.weight_scale,
-                           (const _Float16 *)st->act + j * Kh, nullptr, j == 0 ? zs0 : zs1, H, Kh, tiles1 * (j + 1)};
-            }
-            ka.ldx = I; ka.T = B;
-            if (B <= 16) ob_launch_skinny<true, 1>(ka, 2 * tiles1, s);
-            else if (B <= 32) ob_launch_skinny<true, 2>(ka, 2 * tiles1, s);
-            else ob_launch_skinny<true, 4>(ka, 2 * tiles1, s);
-            if ((rc = ob_launch_status("decode_step_batched(down)"))) return rc;
+            if ((rc = gemm_splitk2(L.down, st->act, I, zs0, zs1, "down"))) return rc;
         } else if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
     }
     // final: residual + LayerNorm(u_down) + final RMSNorm -> x
