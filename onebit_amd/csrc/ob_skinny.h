@@ -44,12 +44,18 @@ struct ObSkinnyArgs {
 
 // tokens x k elements of one phase: 16*RT x 512 (42 / 75 / 142 KB of LDS with the packed rows: three,
 // two or one workgroup per CU)
-#define OB_SKINNY_PKT(RT_) (512 * (RT_))
-#define OB_SKINNY_LDS(RT_) ((size_t)2 * 16 * (RT_) * (512 + 8) * 2 + (size_t)2 * 64 * (512 / 32 + 1) * 4)
+#ifndef OB_SKINNY_PK12
+#define OB_SKINNY_PK12 512                      // k elements per phase for 16 / 32-token tiles.  1024 (half the barriers,
+                                                // 149 KB of LDS at 32 tokens) measured slower in the batched step: 2.80 vs
+                                                // 2.67 ms -- two workgroups no longer share a CU on the wide launches
+#endif
+#define OB_SKINNY_PK(RT_) ((RT_) >= 4 ? 512 : OB_SKINNY_PK12)
+#define OB_SKINNY_PKT(RT_) (OB_SKINNY_PK(RT_) * (RT_))
+#define OB_SKINNY_LDS(RT_) OB_SKINNY_LDS2(RT_, 4)
 // RNT = 16-row tiles per workgroup: 4 (64 rows), or 8 (128 rows) for the wide layers of the batched step --
 // what these launches move is the [T, K] activation block, once per workgroup out of L2 (the slope of the
 // T = 16 / 32 / 64 timings: ~7 TB/s chip-wide); twice the rows per workgroup is half of that traffic.
-#define OB_SKINNY_LDS2(RT_, RNT_) ((size_t)2 * 16 * (RT_) * (512 + 8) * 2 + (size_t)2 * 16 * (RNT_) * (512 / 32 + 1) * 4)
+#define OB_SKINNY_LDS2(RT_, RNT_) ((size_t)2 * 16 * (RT_) * (OB_SKINNY_PK(RT_) + 8) * 2 + (size_t)2 * 16 * (RNT_) * (OB_SKINNY_PK(RT_) / 32 + 1) * 4)
 
 template <bool PARTIAL, int RT, int RNT = 4>
 __global__ __launch_bounds__(512) void ob_skinny_f16_kernel(const ObSkinnyArgs A)
