@@ -142,7 +142,7 @@ int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype);
 
 /* Prefill glue between the q|k|v projections (called with ONEBIT_FLAG_SKIP_LN) and attention, fp16:
  * LayerNorm of the three rows (bitnet.py:118), RoPE on q and k (modeling_bitllama.py:175-181, every op
- * rounded to fp16) and the head transpose (:478-480) in one pass over T = B * S token rows.
+ * rounded to fp16) and the head transpose (:526-528) in one pass over T = B * S token rows.
  * q -> [B, n_heads, S, head_dim]; k, v -> cache rows [b][kv head][past_len + s][head_dim] of caches
  * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim].
  * ONEBIT_FLAG_Q_TOKEN_MAJOR: q stays [B, S, n_heads, head_dim] (a caller whose attention kernel takes

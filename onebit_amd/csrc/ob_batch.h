@@ -167,7 +167,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
 // LayerNorm of the three pre-LayerNorm rows (bitnet.py:118 -- the projections are called with
 // ONEBIT_FLAG_SKIP_LN), RoPE on q and k (apply_rotary_pos_emb, modeling_bitllama.py:175-181: q*cos +
 // rotate_half(q)*sin, every op rounded to fp16) and the [B, S, heads, D] -> [B, heads, S, D] transpose
-// (:478-480) in one pass: q goes to its own [B, H, S, D] tensor, k and v straight into the KV cache rows
+// (:526-528) in one pass: q goes to its own [B, H, S, D] tensor, k and v straight into the KV cache rows
 // [slot][kv head][past + s][D].  Replaces one LayerNorm kernel per projection plus ~8 elementwise torch
 // kernels (cat / mul / add / neg / copy: 37 ms of a 262 ms 7B prefill of 8 x 2048 tokens).
 // ---------------------------------------------------------------------------------------------
