@@ -350,7 +350,8 @@ def measure_prefill_model(model, dev, B=8, S=2048):
     return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "ms_min": round(dmin * 1e3, 1), "iterations": 20,
             "tokens_per_s": round(B * S / dt, 1),
             "onebit_layer_TFLOPs_equivalent": round(2.0 * B * S * w1 / dt / 1e12, 1),
-            "attention": "sdpa", "glue": "onebit_rows_res_ln_rms + onebit_rows_swiglu", "per": "GPU"}
+            "attention": "sdpa", "glue": "onebit_rows_res_ln_rms (writes the consumers' pre-scaled rows) + onebit_rows_qkv_rope + "
+                                         "onebit_rows_swiglu; projections with ONEBIT_FLAG_PRESCALED", "per": "GPU"}
 
 
 def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048):

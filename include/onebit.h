@@ -144,7 +144,8 @@ int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype);
  * LayerNorm of the three rows (bitnet.py:118), RoPE on q and k (modeling_bitllama.py:175-181, every op
  * rounded to fp16) and the head transpose (:526-528) in one pass over T = B * S token rows.
  * q -> [B, n_heads, S, head_dim]; k, v -> cache rows [b][kv head][past_len + s][head_dim] of caches
- * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim].
+ * laid out [slots >= B][n_kv_heads][max_len][head_dim]; cos / sin are [max_pos, head_dim];
+ * head_dim a power of two >= 16.
  * ONEBIT_FLAG_Q_TOKEN_MAJOR: q stays [B, S, n_heads, head_dim] (a caller whose attention kernel takes
  * strided views then gets its output in token-major rows, ready for o_proj without a transpose copy).  */
 #define ONEBIT_FLAG_Q_TOKEN_MAJOR 0x2u

@@ -199,10 +199,24 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
         const int bq = vq[v] ? base : 0, bk = vk[v] ? base : 0;
         const int dq = bq % D, dk = bk % D;
         q8[v] = *reinterpret_cast<const ob_half8 *>(uq + bq);
-        qp8[v] = *reinterpret_cast<const ob_half8 *>(uq + bq + (dq < half ? half : -half));
         k8[v] = *reinterpret_cast<const ob_half8 *>(uk + bk);
-        kp8[v] = *reinterpret_cast<const ob_half8 *>(uk + bk + (dk < half ? half : -half));
         v8[v] = *reinterpret_cast<const ob_half8 *>(uv + bk);
+        (void)dq; (void)dk;
+    }
+    // rotate_half partners: elements d +- D/2 of the same head live D/16 lanes away (8 elements per lane, heads are
+    // aligned groups of D/8 lanes) -- a lane exchange instead of a second pass over the rows.  Lanes beyond the
+    // vector hold clamped copies of lane 0's chunk and exchange among themselves.
+#pragma unroll
+    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        const ob_u32x4 qa = __builtin_bit_cast(ob_u32x4, q8[v]), ka = __builtin_bit_cast(ob_u32x4, k8[v]);
+        ob_u32x4 qb, kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qb[i] = (uint32_t)__shfl_xor((int)qa[i], D >> 4);
+            kb[i] = (uint32_t)__shfl_xor((int)ka[i], D >> 4);
+        }
+        qp8[v] = __builtin_bit_cast(ob_half8, qb);
+        kp8[v] = __builtin_bit_cast(ob_half8, kb);
     }
     const float cq = (float)uq[0], ck = (float)uk[0], cv = (float)uv[0];
     ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};

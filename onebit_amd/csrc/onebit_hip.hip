@@ -739,7 +739,8 @@ extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void
     if (flags & ~ONEBIT_FLAG_Q_TOKEN_MAJOR) return ob_fail(ONEBIT_E_FLAG, "rows_qkv_rope: unknown flags 0x%x", flags);
     if (B < 0 || S < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || past_len < 0)
         return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: bad size");
-    if (head_dim % 16 != 0 || (int64_t)n_heads * head_dim > OB_DEC_MAXV * OB_DEC_THREADS * 8 || n_kv_heads > n_heads)
+    // (power-of-two head_dim: a head is an aligned group of head_dim / 8 lanes, rotate_half partners are a lane exchange)
+    if (head_dim < 16 || (head_dim & (head_dim - 1)) != 0 || (int64_t)n_heads * head_dim > OB_DEC_MAXV * OB_DEC_THREADS * 8 || n_kv_heads > n_heads)
         return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope: heads %d / %d x %d", n_heads, n_kv_heads, head_dim);
     if (past_len + S > max_len || past_len + S > max_pos)
         return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope: %lld + %lld tokens beyond the cache (%lld) or the rope tables (%lld)",

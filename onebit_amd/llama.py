@@ -274,7 +274,8 @@ class OneBitLlamaForCausalLM(nn.Module):
         for li, (layer, kv) in enumerate(zip(m.layers, cache.layers)):
             att = layer.self_attn
             fused_attn = (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
-                          and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous())
+                          and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()
+                          and att.head_dim >= 16 and att.head_dim & (att.head_dim - 1) == 0)
             if u_down is not None:
                 h, x, xs = res_ln_rms(h, u_down, layer.input_layernorm.weight,
                                       (att.q_proj, att.k_proj, att.v_proj) if fused_attn else ())
