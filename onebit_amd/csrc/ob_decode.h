@@ -1086,10 +1086,15 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int p = pg + PG * i;
-        const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
-        const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
-        sreg[i] = p < L ? sv : -INFINITY;
-        lmax = fmaxf(lmax, sreg[i]);
+        sreg[i] = -INFINITY;
+        // (batched step: whole sweeps beyond the sequence are skipped -- uniform per workgroup; with heads x slots
+        // workgroups sharing the SIMDs every masked instruction is somebody else's issue slot)
+        if (BLIND || PG * i < L) {
+            const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
+            const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);
+            sreg[i] = p < L ? sv : -INFINITY;
+            lmax = fmaxf(lmax, sreg[i]);
+        }
     }
     for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
@@ -1119,7 +1124,10 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
     }
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
+    for (int i = 0; i < NI; ++i) {
+        if (BLIND || PG * i < L) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
+        else sreg[i] = 0.f;
+    }
     for (int p0 = 128; p0 < L; p0 += 128) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -1149,11 +1157,13 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int p = pg + PG * i;
-        const float pr = ob_round_h(sreg[i] * inv_l);
-        const ob_half8 vv = p == pos ? vn8 : vreg[i];
-        if (p < L) {
+        if (BLIND || PG * i < L) {
+            const float pr = ob_round_h(sreg[i] * inv_l);
+            const ob_half8 vv = p == pos ? vn8 : vreg[i];
+            if (p < L) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
+                for (int e = 0; e < 8; ++e) o[e] += pr * (float)vv[e];
+            }
         }
     }
     for (int p0 = 128; p0 < L; p0 += 128) {
