@@ -230,3 +230,46 @@ def test_prescaled_prefill_route_forced_on_a_small_model():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "forced_prescaled_child.py")
     r = subprocess.run([sys.executable, child], env=dict(os.environ, OB_GEMM3="2"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced-prescaled ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_rows_glue_scaled_outputs_small_ragged_shapes():
+    """onebit_rows_res_ln_rms with 0..3 scaled outputs and onebit_rows_swiglu with h_next on widths that are not
+    multiples of the 4096-element pass (H = 40, 1000, 5120): x and the residual are unchanged by the extra
+    outputs, every a_i equals fp16(x * h_i) exactly; argument errors are reported."""
+    import ctypes
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    sp = _stream_ptr(dev)
+    g = torch.Generator().manual_seed(17)
+    nul = (ctypes.c_void_p * 3)()
+    for T, H in ((3, 40), (7, 1000), (2, 5120)):
+        hres = torch.randn(T, H, generator=g).half().to(dev)
+        u = (0.4 * torch.randn(T, H, generator=g) + 0.1).half().to(dev)
+        w = (1.0 + 0.2 * torch.randn(H, generator=g)).half().to(dev)
+        hs = [(0.1 * (0.5 + torch.rand(H, generator=g))).half().to(dev) for _ in range(3)]
+        hout0, x0 = torch.empty_like(hres), torch.empty_like(hres)
+        _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout0.data_ptr(), x0.data_ptr(),
+                                              nul, nul, 0, T, H, 1e-6, 1e-5, sp), "rows_res_ln_rms")
+        for n in (1, 2, 3):
+            hout, xs = torch.empty_like(hres), [torch.empty_like(hres) for _ in range(n)]
+            hp = (ctypes.c_void_p * 3)(*[h.data_ptr() for h in hs[:n]])
+            xp = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in xs])
+            _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(), None,
+                                                  hp, xp, n, T, H, 1e-6, 1e-5, sp), "rows_res_ln_rms")
+            assert torch.equal(hout, hout0)
+            for a, h in zip(xs, hs):
+                assert torch.equal(a, x0 * h)
+        ug, uu = (0.5 * torch.randn(T, H, generator=g)).half().to(dev), (0.5 * torch.randn(T, H, generator=g)).half().to(dev)
+        act, act_s = torch.empty_like(ug), torch.empty_like(ug)
+        _lib.check(lib.onebit_rows_swiglu(ug.data_ptr(), uu.data_ptr(), None, act.data_ptr(), T, H, 1e-5, sp), "rows_swiglu")
+        _lib.check(lib.onebit_rows_swiglu(ug.data_ptr(), uu.data_ptr(), hs[0].data_ptr(), act_s.data_ptr(), T, H, 1e-5, sp), "rows_swiglu")
+        assert torch.equal(act_s, act * hs[0])
+    # errors: neither x nor a scaled output; too many scaled outputs; a NULL entry in the list
+    assert lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout0.data_ptr(), None, nul, nul, 0,
+                                      T, H, 1e-6, 1e-5, sp) != 0
+    assert lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout0.data_ptr(), x0.data_ptr(), nul, nul, 4,
+                                      T, H, 1e-6, 1e-5, sp) != 0
+    assert lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout0.data_ptr(), x0.data_ptr(), nul, nul, 1,
+                                      T, H, 1e-6, 1e-5, sp) != 0
