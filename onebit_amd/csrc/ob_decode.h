@@ -862,13 +862,21 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         //    4 digits and 8 waves in the finishing thread -- deterministic, error <= a few 2^-24
         if ((lane & 15) < 4) {
             const float dscale = __uint_as_float((uint32_t)(127 + 8 * (lane & 3)) << 23);
+            // (S - 2 B) * f as fma((float)B, -2 f, (float)S * f): f is a power of two and |S|, |B|, |S - 2 B| < 2^24,
+            // so every step is exact and the value is the same -- two instructions per row instead of four
+            float fa[NPROJ], fb[NPROJ];
+#pragma unroll
+            for (int p = 0; p < NPROJ; ++p) {
+                // a non-finite activation makes the whole output row NaN, as it does in the reference's GEMM
+                const float f = nonfinite[p] ? __builtin_nanf("") : dscale * inv_scale[p];
+                fa[p] = (float)sdig[p] * f;
+                fb[p] = -2.0f * f;
+            }
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                // a non-finite activation makes the whole output row NaN, as it does in the reference's GEMM
-                const float f = nonfinite[j % NPROJ] ? __builtin_nanf("") : dscale * inv_scale[j % NPROJ];
                 float *dst = lds_red + (((j * OB_DEC_WAVES + wave) * 16 + 4 * gq) << 2) + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[4 * r] = (float)(sdig[j % NPROJ] - 2 * acc[j][r]) * f;
+                for (int r = 0; r < 4; ++r) dst[4 * r] = __builtin_fmaf((float)acc[j][r], fb[j % NPROJ], fa[j % NPROJ]);
             }
         }
         __syncthreads();
@@ -876,12 +884,17 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         float uval = 0.f;
         if (fin) {
             const int r = tid & 15;
-            float z = 0.f;
+            // fixed order: (sum over waves of digit 0 + digit 2) + (sum over waves of digit 1 + digit 3), as packed
+            // fp32 adds on the register pairs the 16-byte reads deliver (hipcc turned the scalar form
+            // ((t0 + t1) + (t2 + t3)) into packed adds behind 30 register moves)
+            ob_float2 z2 = {0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < OB_DEC_WAVES; ++w) {
                 const ob_float4 t = *reinterpret_cast<const ob_float4 *>(lds_red + (((jo * OB_DEC_WAVES + w) * 16 + r) << 2));
-                z += (t[0] + t[1]) + (t[2] + t[3]);
+                const ob_float2 lo = {t[0], t[1]}, hi = {t[2], t[3]};
+                z2 += lo + hi;
             }
+            const float z = z2[0] + z2[1];
             const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);   // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
             u_out[n_out] = uh;
             uval = (float)uh;
