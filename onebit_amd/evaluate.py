@@ -17,6 +17,14 @@ Host-side restatements of the two loops the reference drives its inference model
   continuation's log-probabilities summed, plus the "greedy decoding would have produced exactly
   this continuation" flag.  Results are returned in the callers' order.
 
+Multi-GPU: the reference spreads the decoder LAYERS over the visible GPUs by free memory
+(``evaluation/lm_eval/parallel_utils.py:12-36,89-130``, driven by ``nvidia-smi``) because a dense fp16
+13B model does not fit its cards.  The packed model is 0.8-1.6 GB: on MI355X every rank keeps all of it
+and the WORK is sharded instead -- ``perplexity`` windows / ``loglikelihood_tokens`` chunks are dealt
+round-robin to the ranks of a ``torch.distributed`` group (``rank`` / ``world`` / ``group`` arguments;
+RCCL on GPUs, gloo in the CPU tests) and the per-window / per-request results are all-gathered, so every
+rank returns exactly what a single process returns (same values, same summation order).
+
 Both run prefill-shaped work: T = B * S tokens per 1-bit layer, i.e. the MFMA GEMM of
 ``onebit_linear_forward`` with ragged, padded shapes.  The model is called as the reference calls
 its own (``model(inps)`` -> logits ``[B, S, vocab]``); nothing here touches the oracle.
@@ -38,7 +46,7 @@ def _model_logits(model, inps: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def perplexity(model, token_ids: torch.Tensor, seqlen: int, limit: int = -1,
-               logits_dtype: Optional[torch.dtype] = None) -> float:
+               logits_dtype: Optional[torch.dtype] = None, rank: int = 0, world: int = 1, group=None) -> float:
     """PPL of ``token_ids`` ([1, N] long) in windows of ``seqlen`` (lm_eval.py:93-128).
 
     ``logits_dtype``: dtype the loss is computed in.  The reference computes
@@ -54,8 +62,11 @@ def perplexity(model, token_ids: torch.Tensor, seqlen: int, limit: int = -1,
         raise ValueError("fewer tokens than one window")
     dev = next(model.parameters()).device
     loss_fct = nn.CrossEntropyLoss()
-    nlls = []
-    for i in range(nsamples):
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank / world")
+    nwin = nsamples if limit < 0 or limit >= nsamples else limit + 1       # (:123: stops after window index `limit`)
+    mine = torch.zeros(nwin, dtype=torch.float32, device=dev)
+    for i in range(rank, nwin, world):
         batch = token_ids[:, i * seqlen:(i + 1) * seqlen].to(dev)
         logits = _model_logits(model, batch)
         if logits_dtype is not None:
@@ -63,18 +74,24 @@ def perplexity(model, token_ids: torch.Tensor, seqlen: int, limit: int = -1,
         shift_logits = logits[:, :-1, :]
         shift_labels = batch[:, 1:]
         loss = loss_fct(shift_logits.reshape(-1, shift_logits.size(-1)), shift_labels.reshape(-1))
-        nlls.append(loss.float() * seqlen)
-        if i == limit:
-            break
-    return float(torch.exp(torch.stack(nlls).sum() / (nsamples * seqlen)).item())
+        mine[i] = loss.float() * seqlen
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=group)            # disjoint supports: a gather by addition of zeros
+    return float(torch.exp(mine.sum() / (nsamples * seqlen)).item())
 
 
 @torch.no_grad()
 def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence[int]]], batch_size: int,
-                         max_length: int, vocab_size: Optional[int] = None) -> List[Tuple[float, bool]]:
+                         max_length: int, vocab_size: Optional[int] = None, rank: int = 0, world: int = 1,
+                         group=None) -> List[Tuple[float, bool]]:
     """``[(sum log p(continuation | context), is_greedy)]`` for ``requests = [(context_ids,
     continuation_ids)]`` (models_utils.py:257-438).  ``vocab_size`` is the reference's
-    ``[:, :, :self.vocab_size]`` slice (tokenizer vocabulary; default: all logits)."""
+    ``[:, :, :self.vocab_size]`` slice (tokenizer vocabulary; default: all logits).
+    ``world > 1``: chunk ``c`` of the sorted requests is evaluated by rank ``c % world``, the results are
+    exchanged with ``all_gather_object``; every rank returns the complete list."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank / world")
     dev = next(model.parameters()).device
     # Reorderer (models_utils.py:544-568): requests whose concatenated tokens are identical form ONE
     # group, evaluated once with the first member's (context, continuation) split -- the split is
@@ -85,7 +102,9 @@ def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence
         groups.setdefault((-len(toks), toks), []).append(i)
     order = sorted(groups)
     res: List[Optional[Tuple[float, bool]]] = [None] * len(requests)
-    for c0 in range(0, len(order), batch_size):
+    for ci, c0 in enumerate(range(0, len(order), batch_size)):
+        if ci % world != rank:
+            continue
         chunk = order[c0:c0 + batch_size]
         inps, inplens, conts = [], [], []
         padding_length = None
@@ -111,4 +130,12 @@ def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence
             lp = torch.gather(lg, 1, cont_t.unsqueeze(-1)).squeeze(-1)
             for i in groups[key]:
                 res[i] = (float(lp.sum()), is_greedy)
+    if world > 1:
+        import torch.distributed as dist
+        parts: List[Optional[list]] = [None] * world
+        dist.all_gather_object(parts, res, group=group)
+        for part in parts:
+            for i, v in enumerate(part):            # each request was evaluated by exactly one rank
+                if v is not None:
+                    res[i] = v
     return res  # type: ignore[return-value]

@@ -84,3 +84,64 @@ def test_perplexity_windows_limit_and_scaling():
     assert abs(perplexity(m, toks, S, limit=1) - math.exp(sum(nll[:2]) / (4 * S))) < 1e-3
     with np.testing.assert_raises(ValueError):
         perplexity(m, toks[:, :10], S)
+
+
+# ---- data-parallel evaluation over a process group (gloo, world 2 and 3): every rank returns what one process returns
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _eval_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = CausalStub(seed=3)
+        g = torch.Generator().manual_seed(11)
+        ids = torch.randint(0, 50, (1, 7 * 12 + 5), generator=g)
+        reqs = []
+        for n, m in [(5, 3), (9, 1), (2, 6), (14, 2), (5, 3), (3, 3), (8, 4), (1, 1), (6, 5), (11, 2), (4, 4)]:
+            reqs.append((torch.randint(0, 50, (n,), generator=g).tolist(), torch.randint(0, 50, (m,), generator=g).tolist()))
+        reqs[4] = reqs[0]                                       # a duplicate group
+        ref_ppl = [perplexity(model, ids, 12), perplexity(model, ids, 12, limit=3)]
+        ref_ll = loglikelihood_tokens(model, reqs, batch_size=3, max_length=10)
+        model.calls.clear()
+        got_ppl = [perplexity(model, ids, 12, rank=rank, world=world), perplexity(model, ids, 12, limit=3, rank=rank, world=world)]
+        ncalls_ppl = len(model.calls)
+        model.calls.clear()
+        got_ll = loglikelihood_tokens(model, reqs, batch_size=3, max_length=10, rank=rank, world=world)
+        res = [None] * world
+        dist.all_gather_object(res, (got_ppl == ref_ppl, got_ll == ref_ll, ncalls_ppl, len(model.calls)))
+        if rank == 0:
+            out.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_evaluation_equals_single_process():
+    """perplexity windows / loglikelihood chunks dealt round-robin to the ranks of a gloo group: every rank gets the
+    single-process results bit for bit, and the model calls are actually split between the ranks."""
+    import pytest
+    import torch.multiprocessing as mp
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(r[0] and r[1] for r in res), res
+        # 7 windows + 4 windows (limit = 3) and 4 chunks (10 groups of 3) split over the ranks
+        assert sum(r[2] for r in res) == 7 + 4 and max(r[2] for r in res) < 11
+        assert sum(r[3] for r in res) == 4 and max(r[3] for r in res) <= 2
