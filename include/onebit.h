@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 4
+#define ONEBIT_ABI_VERSION 5
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -63,6 +63,13 @@ const char *onebit_last_error(void);
  *   replaces bitnet.py:98-110.  out [N,K] (dtype) of +1 / -1.
  */
 int onebit_pack_signs(const void *w, int dtype, void *packed, int64_t N, int64_t K, void *stream);
+/* onebit_fp16_to_int8: the reference function itself (convert_llama_to_infer_ckpt.py:7-15) on an arbitrary
+ *   tensor s [N,K] (dtype): v = (0 - s + 1) / 2 evaluated in dtype, truncated to uint8 (:10), byte j =
+ *   sum_i v[8j+i] * 2^i mod 256 (:12-13).  On sign values (+1 / -1 / 0) identical to onebit_pack_signs;
+ *   elsewhere it reproduces the reference's arithmetic (its asserts :8-9 are commented out): s = -0.5 packs as
+ *   +1, s = -3 sets the NEXT bit.  Domain: s <= 1 (v >= 0; for s > 1 torch's float -> uint8 conversion is
+ *   implementation-defined; here such elements contribute 0, like NaN).  s 16-byte aligned.               */
+int onebit_fp16_to_int8(const void *s, int dtype, void *packed, int64_t N, int64_t K, void *stream);
 int onebit_unpack_signs(const void *packed, void *out, int dtype, int64_t N, int64_t K, void *stream);
 
 /* ---- forward (bitnet.py:112-122) -------------------------------------------

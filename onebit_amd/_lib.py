@@ -16,7 +16,7 @@ ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
 FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
 FLAG_PRESCALED = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
 _i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
@@ -24,6 +24,7 @@ SYMBOLS = {
     "onebit_abi_version": (_int, []),
     "onebit_last_error": (ctypes.c_char_p, []),
     "onebit_pack_signs": (_int, [_vp, _int, _vp, _i64, _i64, _vp]),
+    "onebit_fp16_to_int8": (_int, [_vp, _int, _vp, _i64, _i64, _vp]),
     "onebit_unpack_signs": (_int, [_vp, _vp, _int, _i64, _i64, _vp]),
     "onebit_linear_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _int]),
     "onebit_linear_forward": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t,

@@ -84,9 +84,26 @@ def pack_signs(weight: torch.Tensor) -> torch.Tensor:
 
 
 def fp16_to_int8(fp16_tensor: torch.Tensor) -> torch.Tensor:
-    """Reference name for the packer (convert_llama_to_infer_ckpt.py:7-15).  Its documented
-    domain is a tensor of +1 / -1 (0 from ``torch.sign`` maps to +1), on which this is identical."""
-    return pack_signs(fp16_tensor)
+    """The reference's packer under its own name (convert_llama_to_infer_ckpt.py:7-15), with the reference's
+    arithmetic on ANY input: ``v = (0 - s + 1) / 2`` in the tensor's dtype, truncated to uint8, bytes LSB-first
+    with the uint8 matmul's wrap -- identical to ``pack_signs`` on +1 / -1 / 0 (what ``torch.sign`` produces),
+    and equal to the reference elsewhere too (s = -0.5 packs as +1; |s| > 1 spills into the next bit), for
+    s <= 1 (``onebit_fp16_to_int8``; fixture tests/golden/pack_nonsign.npz)."""
+    _require_gpu(fp16_tensor, "fp16_to_int8")
+    if fp16_tensor.dim() != 2:
+        raise ValueError("expected a 2-D tensor [N, K]")
+    N, K = fp16_tensor.shape
+    if K % 8 != 0:
+        raise ValueError(f"in_features={K} is not a multiple of 8")     # the reference's view(N, -1, 8) raises (:11)
+    s = fp16_tensor.contiguous()
+    if s.dtype not in (torch.float16, torch.float32):
+        s = s.float()
+    out = torch.empty((N, K // 8), dtype=torch.int8, device=s.device)
+    lib = _lib.load()
+    with torch.cuda.device(s.device):
+        rc = lib.onebit_fp16_to_int8(s.data_ptr(), _dtype_code(s.dtype), out.data_ptr(), N, K, _stream_ptr(s.device))
+    _lib.check(rc, "onebit_fp16_to_int8")
+    return out
 
 
 class BitLinearInf(nn.Module):
@@ -149,7 +166,10 @@ class BitLinearInf(nn.Module):
         (``pre_layernorm_prescaled``): it takes the LDS-DMA GEMM, which reads fp16(x * h) rows."""
         if self.bias is not None or dtype != torch.float16 or self.weight_scale.dtype != torch.float16:
             return False
-        return bool(_lib.load().onebit_linear_prescaled_ok(T, self.in_features, self.out_features, _dtype_code(dtype)))
+        if not self.weight.is_cuda or self.weight.stride(-1) != 1 or self.weight.stride(0) % 16 or self.weight.data_ptr() % 16:
+            return False                                   # what the C side requires of the packed rows for the flag
+        with torch.cuda.device(self.weight.device):        # eligibility depends on the CU count of the device that will run it
+            return bool(_lib.load().onebit_linear_prescaled_ok(T, self.in_features, self.out_features, _dtype_code(dtype)))
 
     def pre_layernorm_prescaled(self, a: torch.Tensor) -> torch.Tensor:
         """``pre_layernorm`` on activations the producer already scaled: ``a = fp16(x * input_factor)``
@@ -199,7 +219,8 @@ class BitLinearInf(nn.Module):
             flags |= _lib.FLAG_PRESCALED
             ws_bytes = 0                                   # the scaled rows ARE the input
         else:
-            ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
+            with torch.cuda.device(x.device):
+                ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
         with torch.cuda.device(x.device):
             rc = lib.onebit_linear_forward(

@@ -288,7 +288,11 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)smem;
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     auto dma16 = [&](const char *base, uint32_t voff, uint32_t lds_addr) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
+        // M0 is saved and restored INSIDE the statement (scalar temporary), so no reserved register is
+        // clobbered from the compiler's point of view: whatever it may keep in M0 across this point survives
+        uint32_t m0_keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_keep) : "s"(lds_addr), "v"(voff), "s"(base) : "memory");
     };
     auto dma = [&](int tile) {
         const uint32_t buf = (uint32_t)tile & (OB_G3_BUFS - 1);

@@ -11,7 +11,6 @@
 #include "ob_linear.h"
 #include "ob_pack.h"
 #include "ob_decode.h"
-#include "ob_decode2.h"
 #include "ob_gemm.h"
 #include "ob_gemm2.h"
 #include "ob_skinny.h"
@@ -79,6 +78,24 @@ extern "C" int onebit_pack_signs(const void *w, int dtype, void *packed, int64_t
         hipLaunchKernelGGL(ob_pack_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float *)w,
                            (uint8_t *)packed, nbytes);
     return ob_launch_status("pack_signs");
+}
+
+extern "C" int onebit_fp16_to_int8(const void *sgn, int dtype, void *packed, int64_t N, int64_t K, void *stream)
+{
+    if (N < 0 || K < 0) return ob_fail(ONEBIT_E_ARG, "fp16_to_int8: negative size");
+    if (K % 8 != 0) return ob_fail(ONEBIT_E_SHAPE, "fp16_to_int8: K=%lld is not a multiple of 8", (long long)K);
+    if (dtype != ONEBIT_F16 && dtype != ONEBIT_F32) return ob_fail(ONEBIT_E_DTYPE, "fp16_to_int8: dtype %d", dtype);
+    if (N == 0 || K == 0) return 0;
+    if (!sgn || !packed) return ob_fail(ONEBIT_E_ARG, "fp16_to_int8: null pointer");
+    if (!ob_aligned(sgn, 16)) return ob_fail(ONEBIT_E_ALIGN, "fp16_to_int8: input must be 16-byte aligned");
+    const int64_t nbytes = N * (K / 8);
+    const int blocks = (int)((nbytes + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ONEBIT_F16)
+        hipLaunchKernelGGL(ob_f2i8_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16 *)sgn, (uint8_t *)packed, nbytes);
+    else
+        hipLaunchKernelGGL(ob_f2i8_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float *)sgn, (uint8_t *)packed, nbytes);
+    return ob_launch_status("fp16_to_int8");
 }
 
 extern "C" int onebit_unpack_signs(const void *packed, void *out, int dtype, int64_t N, int64_t K,
@@ -203,8 +220,11 @@ static void ob_launch_mm16(const void *packed, int64_t ldw_bytes, const void *x,
         else if (T <= 32) OB_GEMM_GO(4, 1, 1, 2);
         else if (T <= 64) OB_GEMM_GO(4, 1, 1, 4);
         else {
-            // large T with K % 64 == 0: the 256 x 256 / 8-wave kernel (ob_gemm2.h); OB_GEMM2=0 keeps the 128 x 128 one, =2 forces it
-            static const int gemm2_env = getenv("OB_GEMM2") ? atoi(getenv("OB_GEMM2")) : 1;
+            // large T without a workspace: the 128 x 128 kernel.  The register-staged 256 x 256 / 8-wave kernel (ob_gemm2.h) issues
+            // its staging loads from inline asm whose in-flight destination registers the compiler cannot model, so it is opt-in
+            // (OB_GEMM2=1: from 4 rounds of tiles, =2: forced on any eligible shape -- the forced-route parity tests); every product
+            // caller passes a workspace and takes the LDS-DMA kernel instead
+            static const int gemm2_env = getenv("OB_GEMM2") ? atoi(getenv("OB_GEMM2")) : 0;
             // (worth it from ~4 rounds of 256 x 256 tiles over the CUs; smaller problems quantise badly)
             const int64_t tiles2 = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + OB_G2_T - 1) / OB_G2_T);
             if (gemm2_env && (tiles2 >= 4 * (int64_t)ob_cu_count() || gemm2_env == 2) && T >= 192 && K % OB_G2_K == 0 && N % 4 == 0 && ldx % 8 == 0) {
@@ -535,49 +555,6 @@ static bool ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStre
     return true;
 }
 
-// ---- role-split kernel (ob_decode2.h): 1024 threads, prologue waves + matrix waves ----
-template <int KV, int MS, int PRO, int NPROJ, bool PST>
-static void ob_launch_dec_gemv2_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
-{
-    static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_dec_gemv2_kernel<KV, MS, PRO, NPROJ, PST>, attr_set, 160 * 1024);
-    hipLaunchKernelGGL((ob_dec_gemv2_kernel<KV, MS, PRO, NPROJ, PST>), dim3(G), dim3(OB_DEC2_THREADS), lds, s, a);
-}
-template <int KV, int MS, int PRO, int NPROJ>
-static void ob_launch_dec_gemv2_t(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
-{
-    // KV = 4 (in_features > 12288): the tile partials of four 256-tile blocks per vector do not fit the
-    // 128-register budget of a 1024-thread workgroup next to the vectors themselves: recompute there
-    if constexpr (PRO == OB_P_RES_LN_RMS && KV < 4) {
-        if (a.st_prev) return ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, true>(a, G, lds, s);
-    }
-    if constexpr (PRO == OB_P_SWIGLU && KV < 4) {
-        if (a.st_gate && a.st_up) return ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, true>(a, G, lds, s);
-    }
-    ob_launch_dec_gemv2_t2<KV, MS, PRO, NPROJ, false>(a, G, lds, s);
-}
-template <int KV, int MS>
-static bool ob_launch_dec_gemv2_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
-{
-    if (a.prologue == OB_P_PLAIN && a.nproj == 1) ob_launch_dec_gemv2_t<KV, MS, OB_P_PLAIN, 1>(a, G, lds, s);
-    else if (a.prologue == OB_P_SWIGLU && a.nproj == 1) ob_launch_dec_gemv2_t<KV, MS, OB_P_SWIGLU, 1>(a, G, lds, s);
-    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 2) ob_launch_dec_gemv2_t<KV, MS, OB_P_RES_LN_RMS, 2>(a, G, lds, s);
-    else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 3) ob_launch_dec_gemv2_t<KV, MS, OB_P_RES_LN_RMS, 3>(a, G, lds, s);
-    else if (a.prologue == OB_P_EMBED_RMS && a.nproj == 3) ob_launch_dec_gemv2_t<KV, MS, OB_P_EMBED_RMS, 3>(a, G, lds, s);
-    else return false;
-    return true;
-}
-// OB_DEC2=1 sends the integer-path launches through the role-split kernel, OB_DEC2=2 the single-chunk
-// launches (o_proj) as well.  Default 0: on the 7B shapes the single-role kernel measures faster
-// (whole token 975 vs 909 tok/s) -- the prologue chain, not the weight stream, is
-// the long pole, and eight prologue waves run it no faster than eight combined waves.
-static int ob_dec2_mode()
-{
-    static int m = -1;
-    if (m < 0) { const char *e = getenv("OB_DEC2"); m = e ? atoi(e) : 0; }
-    return m;
-}
-
 // OB_DECODE_MATH=f16 selects the fp16 sign-expansion kernels for A/B measurements; default is the
 // integer path wherever its alignment requirement holds.
 static int ob_decode_math()
@@ -639,17 +616,6 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
     const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2);
-    {   // role-split kernel for the integer path
-        const size_t lds2 = (size_t)a.nproj * Kpad * 4 + (size_t)MT * 8 * 64 * 4 + 32 * 4 + 8 * 3 * 8 * 4 + 32 * 4;
-        const int mode = ob_dec2_mode();
-        if (aligned && ob_decode_math() == 1 && lds2 <= 160 * 1024 && mode && (use_i8 || mode == 2)) {
-            bool ok2 = false, hit2 = false;
-#define OB_CASE2(P, M) if (!hit2 && KV == P && MS == M) { hit2 = true; ok2 = ob_launch_dec_gemv2_p<P, M>(a, G, lds2, s); }
-            OB_CASE2(1, 1) OB_CASE2(1, 2) OB_CASE2(1, 3) OB_CASE2(1, 4) OB_CASE2(2, 1) OB_CASE2(2, 2) OB_CASE2(3, 1) OB_CASE2(4, 1)
-#undef OB_CASE2
-            if (hit2 && ok2) return ob_launch_status("decode gemv (role-split)");
-        }
-    }
     const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
     if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
     bool ok = false, hit = false;
@@ -1038,8 +1004,10 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         !st->u_o || !st->u_gate || !st->u_up || !st->u_down || !st->logits || !st->part_val || !st->part_idx ||
         !m->embed || !m->final_norm_w || !m->lm_head || !m->rope_cos || !m->rope_sin)
         return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer");
-    if (!st->tile_stats || !ob_aligned(st->tile_stats, 16))
-        return ob_fail(ONEBIT_E_ARG, "decode_step: tile_stats (onebit_decode_stats_floats floats, 16-byte aligned) is required");
+    // tile_stats == NULL (a caller written against ABI <= 2 that zero-initialises the state): every consumer
+    // recomputes its LayerNorm statistics from the vectors -- the kernels' non-PST forms
+    if (st->tile_stats && !ob_aligned(st->tile_stats, 16))
+        return ob_fail(ONEBIT_E_ALIGN, "decode_step: tile_stats must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int H = m->hidden, I = m->intermediate, D = m->head_dim;
     _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
@@ -1048,7 +1016,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     float *ts = st->tile_stats;
     float *ts_q = ts + sl.off[0], *ts_k = ts + sl.off[1], *ts_v = ts + sl.off[2], *ts_o = ts + sl.off[3],
           *ts_gate = ts + sl.off[4], *ts_up = ts + sl.off[5], *ts_down = ts + sl.off[6];
-    if ((m->n_heads * D) % 16 || (m->n_kv_heads * D) % 16 || H % 16 || I % 16)      // partial tiles: every consumer
+    if (!ts || (m->n_heads * D) % 16 || (m->n_kv_heads * D) % 16 || H % 16 || I % 16)  // no buffer / partial tiles: every consumer
         ts_q = ts_k = ts_v = ts_o = ts_gate = ts_up = ts_down = nullptr;             // recomputes its statistics
     int rc;
     for (int l = 0; l < m->n_layers; ++l) {

@@ -275,7 +275,14 @@ class OneBitLlamaForCausalLM(nn.Module):
             att = layer.self_attn
             fused_attn = (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
                           and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()
-                          and att.head_dim >= 16 and att.head_dim & (att.head_dim - 1) == 0)
+                          and att.head_dim >= 16 and att.head_dim & (att.head_dim - 1) == 0
+                          # onebit_rows_qkv_rope writes rows [b < B][kv head][past + s][D] through raw pointers: the
+                          # cache must really have B slots of that geometry in the activations' dtype (a batch-1
+                          # cache reused with B > 1 takes the checked torch path, which raises on the shape)
+                          and all(c.dim() == 4 and c.shape[0] >= B and c.dtype == h.dtype and c.device == h.device
+                                  and tuple(c.shape[1:]) == (att.num_key_value_heads, kv[0].shape[2], att.head_dim)
+                                  for c in kv)
+                          and S <= kv[0].shape[2])
             if u_down is not None:
                 h, x, xs = res_ln_rms(h, u_down, layer.input_layernorm.weight,
                                       (att.q_proj, att.k_proj, att.v_proj) if fused_attn else ())

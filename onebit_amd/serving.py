@@ -65,6 +65,14 @@ class Scheduler:
             raise ValueError("max_batch and max_len must be positive")
         if prefill_chunk is not None and prefill_chunk <= 0:
             raise ValueError("prefill_chunk must be positive")
+        if max_step_tokens is not None:
+            if max_step_tokens < 1:
+                raise ValueError("max_step_tokens must be >= 1")
+            # decode tokens come first in a step; with chunked prefill the budget must leave room for at least one
+            # prompt token once every slot is decoding, or a half-entered prompt holds its KV slot and starves
+            if prefill_chunk is not None and max_step_tokens <= max_batch:
+                raise ValueError("with prefill_chunk, max_step_tokens must exceed max_batch "
+                                 "(one token per decoding slot plus at least one prompt token per step)")
         self.max_batch, self.max_len = max_batch, max_len
         self.max_step_tokens = max_step_tokens
         self.prefill_chunk = prefill_chunk
@@ -332,5 +340,9 @@ class ContinuousBatcher:
     def run(self) -> Dict[int, List[int]]:
         """Drain the queue; {request id: generated tokens}."""
         while not self.sched.idle:
+            before = (len(self.sched.waiting), sum(r.pos + len(r.out) for r in self.sched.running), len(self.sched.finished))
             self.step()
+            after = (len(self.sched.waiting), sum(r.pos + len(r.out) for r in self.sched.running), len(self.sched.finished))
+            if after == before:            # an empty plan with work pending would spin forever
+                raise RuntimeError("ContinuousBatcher.run: no progress (a waiting prompt exceeds the step budget?)")
         return {rid: r.out for rid, r in self.sched.finished.items()}

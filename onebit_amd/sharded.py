@@ -74,7 +74,8 @@ def hip_partial(shard: KShard, x_slice: torch.Tensor) -> torch.Tensor:
     w = shard.weight
     code = _dtype_code(x_slice.dtype)
     # room for the pre-scaled slice: large calls then take the LDS-DMA GEMM
-    ws_bytes = lib.onebit_linear_workspace_bytes(T, Ks, shard.out_features, code)
+    with torch.cuda.device(x_slice.device):         # the eligibility query depends on the CURRENT device's CU count
+        ws_bytes = lib.onebit_linear_workspace_bytes(T, Ks, shard.out_features, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_slice.device) if ws_bytes else None
     with torch.cuda.device(x_slice.device):
         rc = lib.onebit_matmul_partial_ws(w.data_ptr(), w.stride(0), x_slice.data_ptr(), x_slice.stride(0),
@@ -85,8 +86,9 @@ def hip_partial(shard: KShard, x_slice: torch.Tensor) -> torch.Tensor:
     return zp
 
 
-def hip_epilogue(shard: KShard, z: torch.Tensor, dtype: torch.dtype, eps: float = 1e-5) -> torch.Tensor:
-    """y = LayerNorm(g * round(z)) (+ bias) for complete rows through the C ABI."""
+def hip_epilogue(shard: KShard, z: torch.Tensor, dtype: torch.dtype, eps: float = 1e-5, return_u: bool = False):
+    """y = LayerNorm(g * round(z)) (+ bias) for complete rows through the C ABI; with `return_u` also the
+    pre-LayerNorm u = fp16(fp16(z) * g) (bitnet.py:115-116), for parity tests."""
     from . import _lib
     from .bitnet import _dtype_code, _stream_ptr
     lib = _lib.load()
@@ -94,11 +96,13 @@ def hip_epilogue(shard: KShard, z: torch.Tensor, dtype: torch.dtype, eps: float 
     y = torch.empty((T, N), dtype=dtype, device=z.device)
     g = shard.weight_scale.to(dtype)
     b = None if shard.bias is None else shard.bias.to(dtype)
+    u = torch.empty((T, N), dtype=dtype, device=z.device) if return_u else None
     with torch.cuda.device(z.device):
         rc = lib.onebit_scale_layernorm(z.data_ptr(), g.data_ptr(), None if b is None else b.data_ptr(),
-                                        y.data_ptr(), None, T, N, _dtype_code(dtype), eps, 0, _stream_ptr(z.device))
+                                        y.data_ptr(), None if u is None else u.data_ptr(), T, N, _dtype_code(dtype), eps, 0,
+                                        _stream_ptr(z.device))
     _lib.check(rc, "onebit_scale_layernorm")
-    return y
+    return (y, u) if return_u else y
 
 
 def k_sharded_forward(shard: KShard, x: torch.Tensor, group=None, mode: str = "rs_ag",
@@ -225,7 +229,8 @@ def hip_rows_u(shard: NShard, x: torch.Tensor) -> torch.Tensor:
     n = shard.n1 - shard.n0
     code = _dtype_code(x.dtype)
     u = torch.empty((T, n), dtype=x.dtype, device=x.device)
-    ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
+    with torch.cuda.device(x.device):
+        ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     w = shard.weight
     with torch.cuda.device(x.device):

@@ -277,3 +277,50 @@ int ob_oracle_forward_f32_unpack_every_call(const int8_t *packed, const float *x
     free(a); free(u);
     return 0;
 }
+
+/*
+ * The same reference-style forward on `threads` host cores (OpenMP): output rows are dealt to the threads, each
+ * thread rebuilds ITS rows of the dense +-1 matrix (bitnet.py:98-110: still once per call, as the reference
+ * does) and multiplies them -- per row the arithmetic and summation order of the single-thread function above,
+ * so the results are identical.  bench.py's cpu_baseline sweeps the thread count and reports the best.
+ */
+int ob_oracle_forward_f32_unpack_every_call_mt(const int8_t *packed, const float *x, const float *h, const float *g,
+                                               float *y_out, float *scratch, int64_t T, int64_t K, int64_t N,
+                                               float eps, int threads)
+{
+    if (K % 8 != 0) return -1;
+    if (threads < 1) threads = 1;
+    float *a = (float *)malloc(sizeof(float) * (size_t)(K > 0 ? K : 1) * (size_t)(T > 0 ? T : 1));
+    float *u = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * (size_t)(T > 0 ? T : 1));
+    if (!a || !u) { free(a); free(u); return -2; }
+    for (int64_t t = 0; t < T; t++)
+        for (int64_t k = 0; k < K; k++) a[t * K + k] = x[t * K + k] * h[k];
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t n = 0; n < N; n++) {
+        float *w = scratch + n * K;
+        ob_oracle_unpack(packed + n * (K / 8), w, 1, K);
+        for (int64_t t = 0; t < T; t++) {
+            const float *at = a + t * K;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            int64_t k = 0;
+            for (; k + 4 <= K; k += 4) {
+                acc0 += at[k] * w[k]; acc1 += at[k + 1] * w[k + 1];
+                acc2 += at[k + 2] * w[k + 2]; acc3 += at[k + 3] * w[k + 3];
+            }
+            for (; k < K; k++) acc0 += at[k] * w[k];
+            u[t * N + n] = ((acc0 + acc1) + (acc2 + acc3)) * g[n];
+        }
+    }
+    for (int64_t t = 0; t < T; t++) {
+        const float *ut = u + t * N;
+        double mean = 0.0, var = 0.0;
+        for (int64_t n = 0; n < N; n++) mean += ut[n];
+        mean /= (double)N;
+        for (int64_t n = 0; n < N; n++) var += (ut[n] - mean) * (ut[n] - mean);
+        var /= (double)N;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        for (int64_t n = 0; n < N; n++) y_out[t * N + n] = (float)(ut[n] - mean) * rstd;
+    }
+    free(a); free(u);
+    return 0;
+}

@@ -136,6 +136,7 @@ class COracle:
         L.ob_oracle_forward_f32.argtypes = [p, p, p, p, p, p, p, i64, i64, i64, f]
         L.ob_oracle_forward_f16.argtypes = [p, p, p, p, p, p, p, i64, i64, i64, f]
         L.ob_oracle_forward_f32_unpack_every_call.argtypes = [p, p, p, p, p, p, i64, i64, i64, f]
+        L.ob_oracle_forward_f32_unpack_every_call_mt.argtypes = [p, p, p, p, p, p, i64, i64, i64, f, ctypes.c_int]
         L.ob_half_to_float.argtypes = [ctypes.c_uint16]
         L.ob_half_to_float.restype = ctypes.c_float
         L.ob_float_to_half.argtypes = [ctypes.c_float]
@@ -204,8 +205,9 @@ class COracle:
         y = y.reshape(*lead, N)
         return (y, u.reshape(*lead, N)) if return_pre_ln else y
 
-    def forward_f32_unpack_every_call(self, packed, x, h, g, scratch=None, eps=1e-5):
-        """Reference-style CPU path (dense +-1 matrix rebuilt on every call)."""
+    def forward_f32_unpack_every_call(self, packed, x, h, g, scratch=None, eps=1e-5, threads=1):
+        """Reference-style CPU path (dense +-1 matrix rebuilt on every call); threads > 1: the OpenMP form
+        (output rows dealt to the threads, identical results)."""
         p = np.ascontiguousarray(packed).view(np.int8)
         x = np.ascontiguousarray(x, dtype=np.float32)
         lead, K = x.shape[:-1], x.shape[-1]
@@ -214,9 +216,14 @@ class COracle:
         if scratch is None:
             scratch = np.empty((N, K), np.float32)
         y = np.empty((T, N), np.float32)
-        rc = self.lib.ob_oracle_forward_f32_unpack_every_call(
-            self._ptr(p), self._ptr(x), self._ptr(np.ascontiguousarray(h, np.float32)),
-            self._ptr(np.ascontiguousarray(g, np.float32)), self._ptr(y), self._ptr(scratch), T, K, N, eps)
+        if threads and threads > 1:
+            rc = self.lib.ob_oracle_forward_f32_unpack_every_call_mt(
+                self._ptr(p), self._ptr(x), self._ptr(np.ascontiguousarray(h, np.float32)),
+                self._ptr(np.ascontiguousarray(g, np.float32)), self._ptr(y), self._ptr(scratch), T, K, N, eps, int(threads))
+        else:
+            rc = self.lib.ob_oracle_forward_f32_unpack_every_call(
+                self._ptr(p), self._ptr(x), self._ptr(np.ascontiguousarray(h, np.float32)),
+                self._ptr(np.ascontiguousarray(g, np.float32)), self._ptr(y), self._ptr(scratch), T, K, N, eps)
         if rc:
             raise ValueError(f"rc={rc}")
         return y.reshape(*lead, N)

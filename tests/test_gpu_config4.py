@@ -1,0 +1,107 @@
+"""BASELINE config 4 ("LLaMA-13B OneBit decode, hidden-dim sharded across 2/4/8 MI355X") through the HIP
+partial-sum kernels at its real slice shapes, emulated on one device.
+
+Every rank p of a K-sharded `BitLinearInf` holds the byte-column slice `W[:, K_p/8]` of the packed matrix
+(the reference has no counterpart, its layer is bitnet.py:112-122), computes fp32 partial
+sums with `onebit_matmul_partial_ws`, the partials are summed (the all-reduce) and `onebit_scale_layernorm`
+finishes the rows.  Here the n ranks' calls run one after the other on cuda:0 on IN-PLACE slices
+(`copy=False`: row pitch = the full K/8 bytes, slice width K_p/8 = 640 / 1280 / 2560 and 1728 / 3456 / 6912
+bytes at 13B) and the partials are added in rank order -- the arithmetic of the N-rank job without the wire.
+Checked against the oracle's complete layer: u within 2 fp16 ulps, y rel-L2 <= 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP16_ULP = 2.0 ** -10
+SHAPES_13B = [(5120, 5120), (5120, 13824), (13824, 5120)]       # q/k/v/o, gate/up, down
+
+
+def _layer(K, N, seed):
+    rng = np.random.default_rng(seed)
+    packed = rng.integers(0, 256, (N, K // 8), dtype=np.uint8).view(np.int8)
+    flip = lambda n: np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    h = (0.1 * (0.5 + rng.random(K)) * flip(K)).astype(np.float16)
+    g = (0.1 * (0.5 + rng.random(N)) * flip(N)).astype(np.float16)
+    return packed, h, g
+
+
+def _check_u(got, ref, tag, frac=0.02):
+    got, ref = got.astype(np.float32), ref.astype(np.float32)
+    ulp = np.maximum(np.abs(ref), 2.0 ** -12) * FP16_ULP
+    assert (np.abs(got - ref) <= 2.001 * ulp).all(), (tag, float((np.abs(got - ref) / ulp).max()))
+    assert (got != ref).mean() <= frac, (tag, float((got != ref).mean()))
+
+
+@pytest.mark.parametrize("K,N", SHAPES_13B)
+@pytest.mark.parametrize("T", [1, 32])
+def test_k_shards_13b_slices_vs_oracle(coracle, K, N, T):
+    from onebit_amd.sharded import hip_epilogue, hip_partial, k_range, shard_k
+    dev = torch.device("cuda:0")
+    packed, h, g = _layer(K, N, 100 + K // 512 + N // 512)
+    x = np.random.default_rng(7 + T).standard_normal((T, K)).astype(np.float16)
+    W, ht, gt, xt = (torch.from_numpy(a).to(dev) for a in (packed, h, g, x))
+    y_ref, u_ref = coracle.forward_f16(packed, x, h, g, None, return_pre_ln=True)
+    for world in (2, 4, 8):
+        z = torch.zeros(T, N, dtype=torch.float32, device=dev)
+        for rank in range(world):
+            sh = shard_k(W, ht, gt, None, rank, world, copy=False)
+            k0, k1 = k_range(K, rank, world)
+            assert (sh.k0, sh.k1) == (k0, k1) and k0 % 32 == 0 and k1 % 32 == 0
+            assert sh.weight.stride(0) == K // 8 and sh.weight.shape[1] == (k1 - k0) // 8     # in place: pitch != width
+            assert sh.weight.data_ptr() == W.data_ptr() + k0 // 8
+            xs = xt[:, k0:k1]                                                                 # strided activations too
+            zp = hip_partial(sh, xs)
+            assert zp.dtype == torch.float32 and zp.shape == (T, N)
+            z += zp                                                                           # rank order = all-reduce order here
+        y, u = hip_epilogue(sh, z, torch.float16, return_u=True)
+        un, yn = u.cpu().numpy(), y.cpu().numpy()
+        for t in range(T):
+            _check_u(un[t], u_ref[t], "K=%d N=%d T=%d world=%d row %d" % (K, N, T, world, t))
+            rel = np.linalg.norm(yn[t].astype(np.float32) - y_ref[t].astype(np.float32)) / np.linalg.norm(y_ref[t].astype(np.float32))
+            assert rel <= 1e-3, (K, N, T, world, t, rel)
+
+
+def test_k_shard_copy_equals_view():
+    """The rank-local COPY of a slice (what a real rank holds: 1/n of the bytes resident) and the in-place
+    view give the same partial sums bit for bit."""
+    from onebit_amd.sharded import hip_partial, shard_k
+    dev = torch.device("cuda:0")
+    K, N = 13824, 5120
+    packed, h, g = _layer(K, N, 5)
+    W, ht, gt = (torch.from_numpy(a).to(dev) for a in (packed, h, g))
+    x = torch.randn(3, K, generator=torch.Generator().manual_seed(1)).half().to(dev)
+    for world, rank in ((8, 3), (4, 1), (2, 1)):
+        a = shard_k(W, ht, gt, None, rank, world, copy=False)
+        b = shard_k(W, ht, gt, None, rank, world, copy=True)
+        assert b.weight.is_contiguous() and not a.weight.is_contiguous()
+        xs = x[:, a.k0:a.k1]
+        assert torch.equal(hip_partial(a, xs), hip_partial(b, xs.contiguous()))
+
+
+def test_shard_model_k_world1_13b_width():
+    """`shard_model_k` (what bench.py's decode_k_sharded runs on every rank) on a 2-layer model of 13B
+    layer widths at world 1: prefill + 3 decode steps equal the unsharded module path (the same kernels
+    behind a different epilogue entry point: u may differ by an ulp where fp32 partials round differently
+    from the fused kernel's sum, hence the logit tolerance of the other model tests)."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.sharded import KShardedBitLinear, shard_model_k
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=512, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                            num_attention_heads=40, max_position_embeddings=64)
+    ref = build_synthetic_model(cfg, seed=21, device=dev)
+    shd = build_synthetic_model(cfg, seed=21, device=dev)
+    shard_model_k(shd, 0, 1, mode="allreduce", copy=False)
+    assert sum(isinstance(m, KShardedBitLinear) for m in shd.modules()) == 14
+    ids = torch.randint(0, cfg.vocab_size, (1, 9), generator=torch.Generator().manual_seed(2)).to(dev)
+    c0, c1 = ref.new_cache(1, 16), shd.new_cache(1, 16)
+    l0, l1 = ref(ids, c0), shd(ids, c1)
+    scale = float(l0.float().abs().max())
+    assert float((l0.float() - l1.float()).abs().max()) <= 6e-3 * scale
+    tok = l0[:, -1].argmax(-1, keepdim=True)
+    for _ in range(3):
+        l0, l1 = ref(tok, c0), shd(tok, c1)
+        assert float((l0.float() - l1.float()).abs().max()) <= 6e-3 * scale
+        tok = l0[:, -1].argmax(-1, keepdim=True)

@@ -195,6 +195,29 @@ def test_pack_unpack_bit_exact(dev, coracle, golden_dir):
         pack_signs(torch.ones(2, 12, device=dev))
 
 
+def test_fp16_to_int8_on_non_sign_tensors(dev, coracle, golden_dir):
+    """`fp16_to_int8` is the reference function, not only on +-1: convert_llama_to_infer_ckpt.py:10 truncates
+    (0 - s + 1) / 2 to uint8 and the uint8 matmul (:12-13) wraps -- s = -0.5 packs as +1, s = -3 sets the NEXT bit.
+    Bit-exact against bytes the reference itself produced (pack_nonsign.npz), fp32 and fp16 inputs, and against
+    the oracle on a larger random tensor of the same domain (s <= 1)."""
+    from onebit_amd import fp16_to_int8, pack_signs
+    z = np.load(os.path.join(golden_dir, "pack_nonsign.npz"))
+    for i in range(int(z["n_cases"])):
+        s = z[f"s_{i}"]
+        for dt, name in ((torch.float32, "f32"), (torch.float16, "f16")):
+            got = fp16_to_int8(_t(s, dev).to(dt)).cpu().numpy()
+            np.testing.assert_array_equal(got, z[f"packed_{name}_{i}"])
+    rng = np.random.default_rng(17)
+    vals = np.array([-509.0, -64.0, -3.0, -2.5, -1.5, -1.0, -0.5, 0.0, 0.5, 1.0], np.float32)
+    s = vals[rng.integers(0, len(vals), (96, 4096))]
+    np.testing.assert_array_equal(fp16_to_int8(_t(s, dev)).cpu().numpy(), coracle.fp16_to_int8(s))
+    # on sign values the two packers agree (what the converter feeds it, :30)
+    sg = np.sign(rng.standard_normal((64, 512))).astype(np.float32)
+    assert torch.equal(fp16_to_int8(_t(sg, dev)), pack_signs(_t(sg, dev)))
+    with pytest.raises(ValueError):
+        fp16_to_int8(torch.ones(2, 12, device=dev))
+
+
 def test_sign_flip_and_row_permutation_properties(dev):
     """Size-independent properties at the full 4096 -> 11008 shape: complementing every weight bit
     negates the output exactly (LN(-u) = -LN(u), fp16 rounding is sign-symmetric); permuting weight

@@ -29,6 +29,18 @@ def test_pack_matches_reference(golden_dir, coracle):
     np.testing.assert_array_equal(coracle.pack_signs(z["latent_w"]), z["latent_packed"])
 
 
+def test_fp16_to_int8_non_sign_values(golden_dir, coracle):
+    """The reference's packer on tensors that are not +-1 (its asserts are commented out,
+    convert_llama_to_infer_ckpt.py:8-9): truncation of (1 - s) / 2 and the uint8 wrap, both oracle statements
+    against bytes the reference produced (tests/golden/gen_goldens_pack_nonsign.py)."""
+    z = _load(golden_dir, "pack_nonsign.npz")
+    for i in range(int(z["n_cases"])):
+        s = z[f"s_{i}"]
+        for dn in ("f32", "f16"):
+            np.testing.assert_array_equal(coracle.fp16_to_int8(s), z[f"packed_{dn}_{i}"])
+            np.testing.assert_array_equal(O.np_fp16_to_int8(s), z[f"packed_{dn}_{i}"])
+
+
 def test_pack_engineered_bytes(golden_dir):
     z = _load(golden_dir, "pack.npz")
     row0 = z["packed_f32_1"][0].view(np.uint8)       # (5, 32) case, row 0

@@ -83,3 +83,24 @@ def test_scheduler_chunked_prefill_with_token_budget():
     assert sorted(r.rid for r in done) == [a, b] and s.finished[a].out == [41] and s.finished[b].out == [42]
     with pytest.raises(ValueError):
         Scheduler(2, 8, prefill_chunk=0)
+
+
+def test_scheduler_rejects_budgets_that_cannot_progress():
+    """A step budget that leaves no room for progress is refused at construction (round-2 review): zero / negative
+    budgets, and with chunked prefill a budget that every decoding slot's token can exhaust."""
+    import pytest
+    with pytest.raises(ValueError):
+        Scheduler(max_batch=4, max_len=32, max_step_tokens=0)
+    with pytest.raises(ValueError):
+        Scheduler(max_batch=4, max_len=32, max_step_tokens=4, prefill_chunk=2)
+    s = Scheduler(max_batch=4, max_len=32, max_step_tokens=5, prefill_chunk=2)
+    for _ in range(5):
+        s.add([1, 2, 3, 4, 5, 6, 7], 3)
+    steps = 0
+    while not s.idle:                               # every step makes progress: no starvation of entering prompts
+        items = s.plan()
+        assert items and sum(len(i.tokens) for i in items) <= 5
+        s.commit(items, [9] * len(items))
+        steps += 1
+        assert steps < 200
+    assert len(s.finished) == 5

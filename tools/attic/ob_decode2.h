@@ -1,3 +1,7 @@
+// NOT part of the product build (moved out of onebit_amd/csrc in round 3: measured slower than the single-role
+// kernel, 909 vs 975 tok/s).  Kept for reference; to try it again, include it after
+// ob_decode.h in onebit_hip.hip and restore the launcher from git history (commit 3b2a16b).
+//
 // Role-split decode GEMV (batch 1, integer sign path, aligned shapes): the kernel onebit_decode_step
 // launches for q|k|v, gate|up and down.
 //
