@@ -294,6 +294,25 @@ typedef struct onebit_fused_in {
 int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,
                       const onebit_fused_in_t *in, void *stream);
 
+/* ---- train-mode layer: the reference's BitLinear + SignSTE on LATENT weights (bitnet.py:14-28, 58-68),
+ * SURVEY.md section 8 rows a8 / f4 (forward and backward for knowledge-distillation training on MI355X).
+ * All tensors of one call share `dtype` (ONEBIT_F16 / ONEBIT_F32); row-major, contiguous.
+ *   forward   y[T,N] = LayerNorm( g * ( (x * h) . sign(W)^T ) ) (+ bias);   W [N,K] full precision, sign(0) = 0 (:18)
+ *             z_save [T,N] (dtype) receives the GEMM output before * g, ln_stats [T,2] fp32 {mean, rstd}: what the
+ *             backward pass reads instead of recomputing the GEMM.
+ *   backward  from gy [T,N]: gx [T,K], gw [N,K] = (gz^T . (x*h)) * (1.001 - tanh(W)^2) (the STE, :21-23), gh [K],
+ *             gg [N], gbias [N] (optional).  workspace: onebit_train_workspace_bytes(T,K,N,dtype), 16-byte aligned.
+ * fp16: MFMA 16x16x16 f16 with fp32 accumulation, every tensor-level op of the reference rounded once to fp16;
+ * fp32: MFMA 16x16x4 f32.  Deterministic (no atomics: column sums have a fixed order).                          */
+size_t onebit_train_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype);
+int onebit_train_forward(const void *x, const void *w_latent, const void *h, const void *g, const void *bias_or_null,
+                         void *y, void *z_save, float *ln_stats, int64_t T, int64_t K, int64_t N, int dtype,
+                         float ln_eps, void *stream);
+int onebit_train_backward(const void *gy, const void *x, const void *w_latent, const void *h, const void *g,
+                          const void *z_save, const float *ln_stats, void *gx, void *gw, void *gh, void *gg,
+                          void *gbias_or_null, void *workspace, size_t workspace_bytes, int64_t T, int64_t K,
+                          int64_t N, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

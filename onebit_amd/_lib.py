@@ -44,6 +44,9 @@ SYMBOLS = {
     "onebit_decode_step": (_int, [_vp, _vp, _vp]),      # (onebit_model_t*, onebit_decode_state_t*, stream)
     "onebit_decode_step_batched": (_int, [_vp, _vp, _vp]),   # (onebit_model_t*, onebit_batch_state_t*, stream)
     "onebit_fused_gemv": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
+    "onebit_train_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _int]),
+    "onebit_train_forward": (_int, [_vp] * 8 + [_i64, _i64, _i64, _int, _f, _vp]),
+    "onebit_train_backward": (_int, [_vp] * 13 + [ctypes.c_size_t, _i64, _i64, _i64, _int, _vp]),
 }
 
 _lock = threading.Lock()

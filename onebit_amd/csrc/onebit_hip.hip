@@ -15,6 +15,7 @@
 #include "ob_gemm2.h"
 #include "ob_skinny.h"
 #include "ob_batch.h"
+#include "ob_train.h"
 
 static thread_local char g_err[256] = "";
 
@@ -1114,4 +1115,116 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     hipLaunchKernelGGL(ob_dec_argmax_kernel, dim3(1), dim3(256), 0, s, (const float *)st->part_val,
                        (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out, m->vocab);
     return ob_launch_status("decode_step(argmax)");
+}
+
+// ------------------------------------------------------------ train-mode layer --
+// onebit_train_forward / onebit_train_backward: bitnet.py:14-28 (SignSTE) and :58-68 (BitLinear.forward)
+
+template <typename TI, bool RCA, bool RCB, int TXA, int TXB, int EPI>
+static void ob_launch_tgemm(const ObTGemmArgs &a, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.N + OB_TG_BN - 1) / OB_TG_BN), (unsigned)((a.M + OB_TG_BM - 1) / OB_TG_BM));
+    hipLaunchKernelGGL((ob_tgemm_kernel<TI, RCA, RCB, TXA, TXB, EPI>), grid, dim3(OB_TG_THREADS), 0, s, a);
+}
+
+static size_t ob_train_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t onebit_train_workspace_bytes(int64_t T, int64_t K, int64_t N, int dtype)
+{
+    if (T <= 0 || K <= 0 || N <= 0) return 0;
+    const size_t sz = dtype == ONEBIT_F32 ? 4 : 2;
+    return ob_train_align((size_t)T * N * sz) + ob_train_align((size_t)T * K * sz) + ob_train_align((size_t)T * 2 * sizeof(float));
+}
+
+static int ob_train_check(const char *what, int64_t T, int64_t K, int64_t N, int dtype)
+{
+    if (T < 0 || K < 0 || N < 0) return ob_fail(ONEBIT_E_ARG, "%s: negative size", what);
+    if (dtype != ONEBIT_F16 && dtype != ONEBIT_F32) return ob_fail(ONEBIT_E_DTYPE, "%s: dtype %d", what, dtype);
+    if (T > 0x7fffffffLL || K > 0x7fffffffLL || N > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "%s: dimension too large", what);
+    return 0;
+}
+
+template <typename TI>
+static int ob_train_forward_t(const void *x, const void *w, const void *h, const void *g, const void *bias, void *y, void *z,
+                              float *stats, int64_t T, int64_t K, int64_t N, float eps, hipStream_t s)
+{
+    ObTGemmArgs a = {};
+    a.A = x; a.lda = K; a.va = h;            // A(t, k) = x[t, k] * h[k]
+    a.B = w; a.ldb = K;                      // B(n, k) = sign(W[n, k])
+    a.C = z; a.ldc = N; a.M = (int)T; a.N = (int)N; a.R = (int)K;
+    ob_launch_tgemm<TI, true, true, OB_TX_SCALE_R, OB_TX_SIGN, OB_TE_PLAIN>(a, s);
+    int rc = ob_launch_status("train_forward(gemm)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((ob_train_ln_fwd_kernel<TI>), dim3((unsigned)T), dim3(256), 0, s, (const TI *)z, (const TI *)g, (const TI *)bias,
+                       (TI *)y, stats, (int)N, eps);
+    return ob_launch_status("train_forward(layernorm)");
+}
+
+extern "C" int onebit_train_forward(const void *x, const void *w_latent, const void *h, const void *g, const void *bias_or_null,
+                                    void *y, void *z_save, float *ln_stats, int64_t T, int64_t K, int64_t N, int dtype,
+                                    float ln_eps, void *stream)
+{
+    int rc = ob_train_check("train_forward", T, K, N, dtype);
+    if (rc) return rc;
+    if (T == 0 || N == 0) return 0;
+    if (K == 0) return ob_fail(ONEBIT_E_SHAPE, "train_forward: in_features = 0");
+    if (!x || !w_latent || !h || !g || !y || !z_save || !ln_stats) return ob_fail(ONEBIT_E_ARG, "train_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == ONEBIT_F16 ? ob_train_forward_t<_Float16>(x, w_latent, h, g, bias_or_null, y, z_save, ln_stats, T, K, N, ln_eps, s)
+                               : ob_train_forward_t<float>(x, w_latent, h, g, bias_or_null, y, z_save, ln_stats, T, K, N, ln_eps, s);
+}
+
+template <typename TI>
+static int ob_train_backward_t(const void *gy, const void *x, const void *w, const void *h, const void *g, const void *z,
+                               const float *stats, void *gx, void *gw, void *gh, void *gg, void *gbias, char *ws,
+                               int64_t T, int64_t K, int64_t N, hipStream_t s)
+{
+    TI *gz = (TI *)ws;
+    TI *ga = (TI *)(ws + ob_train_align((size_t)T * N * sizeof(TI)));
+    float *rowc = (float *)(ws + ob_train_align((size_t)T * N * sizeof(TI)) + ob_train_align((size_t)T * K * sizeof(TI)));
+    int rc;
+    // 1. through the LayerNorm and * g: gz [T, N]; column sums gg, gbias
+    hipLaunchKernelGGL((ob_train_ln_bwd_kernel<TI>), dim3((unsigned)T), dim3(256), 0, s, (const TI *)gy, (const TI *)z, (const TI *)g, stats, gz, rowc, (int)N);
+    if ((rc = ob_launch_status("train_backward(layernorm)"))) return rc;
+    hipLaunchKernelGGL((ob_train_cols_ln_kernel<TI>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, (const TI *)gy, (const TI *)z, (const TI *)g, stats,
+                       (const float *)rowc, (TI *)gg, (TI *)gbias, (int)T, (int)N);
+    if ((rc = ob_launch_status("train_backward(gg)"))) return rc;
+    // 2. ga [T, K] = gz . sign(W);  gx = ga * h;  gh = sum_t ga * x
+    {
+        ObTGemmArgs a = {};
+        a.A = gz; a.lda = N;                 // A(t, n) = gz[t, n]            (n contiguous)
+        a.B = w; a.ldb = K;                  // B(k, n) = sign(W[n, k])        (k = output index, contiguous)
+        a.C = ga; a.C2 = gx; a.vc = h; a.ldc = K; a.M = (int)T; a.N = (int)K; a.R = (int)N;
+        ob_launch_tgemm<TI, true, false, OB_TX_NONE, OB_TX_SIGN, OB_TE_GX>(a, s);
+        if ((rc = ob_launch_status("train_backward(grad input)"))) return rc;
+        hipLaunchKernelGGL((ob_train_cols_gh_kernel<TI>), dim3((unsigned)((K + 63) / 64)), dim3(256), 0, s, (const TI *)ga, (const TI *)x, (TI *)gh, (int)T, (int)K);
+        if ((rc = ob_launch_status("train_backward(gh)"))) return rc;
+    }
+    // 3. gW [N, K] = (gz^T . (x * h)) * (1.001 - tanh(W)^2)
+    {
+        ObTGemmArgs a = {};
+        a.A = gz; a.lda = N;                 // A(n, t) = gz[t, n]            (n = output index, contiguous)
+        a.B = x; a.ldb = K; a.vb = h;        // B(k, t) = x[t, k] * h[k]      (k = output index, contiguous)
+        a.C = gw; a.vc = w; a.ldc = K; a.M = (int)N; a.N = (int)K; a.R = (int)T;
+        ob_launch_tgemm<TI, false, false, OB_TX_NONE, OB_TX_SCALE_I, OB_TE_STE>(a, s);
+        if ((rc = ob_launch_status("train_backward(grad weight)"))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int onebit_train_backward(const void *gy, const void *x, const void *w_latent, const void *h, const void *g,
+                                     const void *z_save, const float *ln_stats, void *gx, void *gw, void *gh, void *gg,
+                                     void *gbias_or_null, void *workspace, size_t workspace_bytes, int64_t T, int64_t K,
+                                     int64_t N, int dtype, void *stream)
+{
+    int rc = ob_train_check("train_backward", T, K, N, dtype);
+    if (rc) return rc;
+    if (T == 0 || N == 0 || K == 0) return ob_fail(ONEBIT_E_SHAPE, "train_backward: empty problem");
+    if (!gy || !x || !w_latent || !h || !g || !z_save || !ln_stats || !gx || !gw || !gh || !gg)
+        return ob_fail(ONEBIT_E_ARG, "train_backward: null pointer");
+    if (!workspace || workspace_bytes < onebit_train_workspace_bytes(T, K, N, dtype) || !ob_aligned(workspace, 16))
+        return ob_fail(ONEBIT_E_WSPACE, "train_backward: needs %zu bytes of 16-byte aligned workspace", onebit_train_workspace_bytes(T, K, N, dtype));
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == ONEBIT_F16 ? ob_train_backward_t<_Float16>(gy, x, w_latent, h, g, z_save, ln_stats, gx, gw, gh, gg, gbias_or_null, (char *)workspace, T, K, N, s)
+                               : ob_train_backward_t<float>(gy, x, w_latent, h, g, z_save, ln_stats, gx, gw, gh, gg, gbias_or_null, (char *)workspace, T, K, N, s);
 }

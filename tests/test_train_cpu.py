@@ -1,11 +1,11 @@
-"""Train-mode BitLinear / SignSTE (onebit_amd/train.py) against forward outputs and gradients recorded
+"""Train-mode BitLinear / SignSTE torch restatement (oracle/train_ref.py, the checker of the HIP layer) against forward outputs and gradients recorded
 from the reference's own class (tests/golden/gen_goldens_train.py), and its relation to the packed layer."""
 import os
 
 import numpy as np
 import torch
 
-from onebit_amd.train import BitLinear
+from oracle.train_ref import BitLinear
 
 
 def _load(golden_dir):
