@@ -350,11 +350,11 @@ def measure_prefill_model(model, dev, B=8, S=2048):
     return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "ms_min": round(dmin * 1e3, 1), "iterations": 20,
             "tokens_per_s": round(B * S / dt, 1),
             "onebit_layer_TFLOPs_equivalent": round(2.0 * B * S * w1 / dt / 1e12, 1),
-            "attention": "sdpa", "glue": "onebit_rows_res_ln_rms (writes the consumers' pre-scaled rows) + onebit_rows_qkv_rope + "
+            "attention": "torch SDPA (AOTriton kernel)", "glue": "onebit_rows_res_ln_rms (writes the consumers' pre-scaled rows) + onebit_rows_qkv_rope + "
                                          "onebit_rows_swiglu; projections with ONEBIT_FLAG_PRESCALED", "per": "GPU"}
 
 
-def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048):
+def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048, tp_kwargs=None, timed=None):
     """BASELINE configs[2] under model-level tensor parallelism (onebit_amd/tp.py): q|k|v by head ->
     local attention -> o K-sharded, gate|up N-sharded -> down K-sharded; two activation exchanges
     (reduce_scatter fp32 + all_gather fp16 of [T, hidden]) per layer over RCCL.  Every rank holds the
@@ -363,13 +363,18 @@ def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048):
     cfg = model.config
     S = min(S, cfg.max_position_embeddings)
     ids = torch.randint(0, cfg.vocab_size, (B, S), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev)
-    tp = TensorParallelPrefill(model, rank, world, attention="sdpa")
+    # (tp_kwargs / timed: the world-2 gloo test runs THIS function on CPU with stand-in compute callbacks and a wall-clock
+    # timer, so the control flow the driver launches on N GPUs has executed with more than one rank)
+    tp = TensorParallelPrefill(model, rank, world, **(tp_kwargs or dict(attention="sdpa")))
+    timed = timed or _timed
     try:
-        tp(ids[:1, :128], gather_logits=False)
-        dt, dmin = _timed(lambda: tp(ids, gather_logits=False), dev, world, warm=2, iters=20)
+        tp(ids[:1, :min(128, S)], gather_logits=False)
+        dt, dmin = timed(lambda: tp(ids, gather_logits=False), dev, world, warm=2, iters=20)
     finally:
+        tp_fused = bool(tp.fused)
         del tp
-        torch.cuda.empty_cache()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
     H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     w1 = L * (4 * H * H + 3 * H * I)
     T = B * S
@@ -377,7 +382,8 @@ def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048):
             "tokens_per_s": round(T / dt, 1), "onebit_layer_TFLOPs_equivalent": round(2.0 * T * w1 / dt / 1e12, 1),
             "exchanges_per_layer": 2 if world > 1 else 0,
             "bytes_per_exchange_per_rank": (T * H * 4 + T * H * 2) if world > 1 else 0,
-            "attention": "sdpa on the local heads", "logits": "own token rows only (not gathered)"}
+            "attention": "torch SDPA (AOTriton kernel) on the local heads", "logits": "own token rows only (not gathered)",
+            "glue": "fused row kernels (onebit_rows_qkv_rope_stats / onebit_rows_res_ln_rms / onebit_rows_swiglu_stats)" if tp_fused else "torch ops"}
 
 
 def measure_cpu_baseline(cfg):

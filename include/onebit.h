@@ -146,6 +146,11 @@ int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *
 int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next_or_null, void *act, int64_t T,
                        int64_t I, float ln_eps, void *stream);
 int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype);
+/* The same with the LayerNorm statistics GIVEN (row_stats [T, 4] fp32: {mean, rstd} of the complete gate row, then of
+ * the complete up row; 16-byte aligned): for a tensor-parallel rank whose u_gate / u_up hold only its column slice
+ * of the rows (onebit_row_stats per rank -> all-gather -> parallel-variance combine).  row_stats NULL = onebit_rows_swiglu. */
+int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, const void *h_next_or_null, const float *row_stats,
+                             void *act, int64_t T, int64_t I, float ln_eps, void *stream);
 
 /* Prefill glue between the q|k|v projections (called with ONEBIT_FLAG_SKIP_LN) and attention, fp16:
  * LayerNorm of the three rows (bitnet.py:118), RoPE on q and k (modeling_bitllama.py:175-181, every op
@@ -160,6 +165,14 @@ int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, cons
                          void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
                          int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
                          float ln_eps, unsigned flags, void *stream);
+
+/* The same with the LayerNorm statistics GIVEN (row_stats [T, 6] fp32: {mean, rstd} of the complete q, k and v rows):
+ * tensor-parallel ranks pass the rows of their own heads (n_heads / n_kv_heads = local counts) and statistics combined
+ * across ranks.  row_stats NULL = onebit_rows_qkv_rope. */
+int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                               const float *row_stats, void *q, void *k_cache, void *v_cache, int64_t B, int64_t S,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len,
+                               int64_t max_pos, float ln_eps, unsigned flags, void *stream);
 
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's

@@ -10,7 +10,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libonebit_hip.so")
+# ONEBIT_LIB: an alternative build of the SAME sources (A/B builds made by tools/variant_bench.py with -D switches);
+# never a different implementation -- the ABI version and every symbol are still checked below
+LIB_PATH = os.environ.get("ONEBIT_LIB") or os.path.join(_HERE, "csrc", "libonebit_hip.so")
 
 ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
@@ -37,6 +39,8 @@ SYMBOLS = {
     "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _f, _f, _vp]),
     "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
     "onebit_linear_prescaled_ok": (_int, [_i64, _i64, _i64, _int]),
+    "onebit_rows_swiglu_stats": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    "onebit_rows_qkv_rope_stats": (_int, [_vp] * 9 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),

@@ -116,6 +116,8 @@ struct ObBSwigluArgs {
     int I;
     float ln_eps;
     const _Float16 *h_next;          // optional: act <- fp16(act * h_next), the consumer's pre-scaled activations
+    const float *ext;                // optional [B, 4] {mean, rstd} of the COMPLETE gate and up rows: the rows given here are a
+                                     // column slice (tensor-parallel N-shard), their statistics were combined across ranks
 };
 
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSwigluArgs A)
@@ -132,16 +134,21 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
         g8[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + row + (valid[v] ? base : 0));
         u8[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + row + (valid[v] ? base : 0));
     }
-    const float c0 = (float)A.u_gate[row], c1 = (float)A.u_up[row];
-    ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v)
-        if (valid[v]) { ob_stats8(g8[v], c0, sg2, qg2); ob_stats8(u8[v], c1, su2, qu2); }
-    float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
-    ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
     float mg, rg, mu, ru;
-    ob_ln_stats(s[0], s[1], c0, I, A.ln_eps, mg, rg);
-    ob_ln_stats(s[2], s[3], c1, I, A.ln_eps, mu, ru);
+    if (A.ext) {                                            // uniform per launch
+        const ob_float4 e = *reinterpret_cast<const ob_float4 *>(A.ext + (size_t)blockIdx.x * 4);
+        mg = e[0]; rg = e[1]; mu = e[2]; ru = e[3];
+    } else {
+        const float c0 = (float)A.u_gate[row], c1 = (float)A.u_up[row];
+        ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < OB_DEC_MAXV; ++v)
+            if (valid[v]) { ob_stats8(g8[v], c0, sg2, qg2); ob_stats8(u8[v], c1, su2, qu2); }
+        float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
+        ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
+        ob_ln_stats(s[0], s[1], c0, I, A.ln_eps, mg, rg);
+        ob_ln_stats(s[2], s[3], c1, I, A.ln_eps, mu, ru);
+    }
     const float ng = -mg * rg, nu = -mu * ru;
 #pragma unroll
     for (int v = 0; v < OB_DEC_MAXV; ++v) {
@@ -179,6 +186,8 @@ struct ObQkvRopeArgs {
     _Float16 *kcache, *vcache;           // [slots, Hkv, max_len, D]
     int S, H, Hkv, D, past, max_len, q_bshd;
     float ln_eps;
+    const float *ext;                    // optional [T, 6] {mean, rstd} of the COMPLETE q, k, v rows (tensor-parallel: the rows
+                                         // given here hold the rank's heads only)
 };
 
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkvRopeArgs A)
@@ -218,21 +227,26 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
         qp8[v] = __builtin_bit_cast(ob_half8, qb);
         kp8[v] = __builtin_bit_cast(ob_half8, kb);
     }
-    const float cq = (float)uq[0], ck = (float)uk[0], cv = (float)uv[0];
-    ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
-        if (vq[v]) ob_stats8(q8[v], cq, a2[0], a2[1]);
-        if (vk[v]) { ob_stats8(k8[v], ck, a2[2], a2[3]); ob_stats8(v8[v], cv, a2[4], a2[5]); }
-    }
-    float st[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) st[i] = a2[i][0] + a2[i][1];
-    ob_block_sum_n<6, OB_DEC_WAVES>(st, red);
     float mq, rq, mk, rk, mv, rv;
-    ob_ln_stats(st[0], st[1], cq, NQ, A.ln_eps, mq, rq);
-    ob_ln_stats(st[2], st[3], ck, NK, A.ln_eps, mk, rk);
-    ob_ln_stats(st[4], st[5], cv, NK, A.ln_eps, mv, rv);
+    if (A.ext) {                                            // uniform per launch
+        const float *e = A.ext + (size_t)t * 6;
+        mq = e[0]; rq = e[1]; mk = e[2]; rk = e[3]; mv = e[4]; rv = e[5];
+    } else {
+        const float cq = (float)uq[0], ck = (float)uk[0], cv = (float)uv[0];
+        ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int v = 0; v < OB_DEC_MAXV; ++v) {
+            if (vq[v]) ob_stats8(q8[v], cq, a2[0], a2[1]);
+            if (vk[v]) { ob_stats8(k8[v], ck, a2[2], a2[3]); ob_stats8(v8[v], cv, a2[4], a2[5]); }
+        }
+        float st[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st[i] = a2[i][0] + a2[i][1];
+        ob_block_sum_n<6, OB_DEC_WAVES>(st, red);
+        ob_ln_stats(st[0], st[1], cq, NQ, A.ln_eps, mq, rq);
+        ob_ln_stats(st[2], st[3], ck, NK, A.ln_eps, mk, rk);
+        ob_ln_stats(st[4], st[5], cv, NK, A.ln_eps, mv, rv);
+    }
     const _Float16 *cosr = A.cos + (int64_t)pos * D, *sinr = A.sin + (int64_t)pos * D;
 #pragma unroll
     for (int v = 0; v < OB_DEC_MAXV; ++v) {

@@ -28,6 +28,9 @@
 #endif
 #define OB_DEC_WAVES (OB_DEC_THREADS / 64)
 #define OB_DEC_MAXV 4            // per-thread vectors of 8 halves: vector widths up to 16384
+#ifndef OB_SMFMA
+#define OB_SMFMA 1               // integer path: the digit sums S come from the matrix pipe (see the kernel); 0 = v_dot4 + DPP
+#endif
 
 struct ObProj {
     const uint32_t *w;           // packed signs [N, ldw words]
@@ -380,6 +383,10 @@ template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
     constexpr int MT = MS * NPROJ;
+    // digit sums from the matrix pipe where several projections share the launch (gate|up, q|k|v: measured 7.16 -> 6.66 us
+    // and 6.57 -> 6.6 us per launch); a single-projection launch with KV = 3 chunks per wave (down) would double its MFMA
+    // count for the same saving and measured slower (7.22 -> 7.50 us): it keeps v_dot4 + DPP
+    constexpr bool SMF = OB_SMFMA && NPROJ >= 2;
     // PST: LayerNorm statistics of the prologue inputs come from the producers' per-tile partials
 #ifdef OB_STRIDED_LOADS                     // A/B switch (tools/phase_probe.py): 4-byte strided prologue loads, no transpose
     constexpr bool SD = MATH == 1;
@@ -782,8 +789,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                     T[s2][1] = __builtin_amdgcn_perm(w0, u0, 0x07060302u);
                     T[s2][2] = __builtin_amdgcn_perm(w1, u1, 0x05040100u);
                     T[s2][3] = __builtin_amdgcn_perm(w1, u1, 0x07060302u);
+                    if (!SMF) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) D[c] = __builtin_amdgcn_sdot4((int)T[s2][c], s2 ? vj1 : vj0, D[c], false);
+                        for (int c = 0; c < 4; ++c) D[c] = __builtin_amdgcn_sdot4((int)T[s2][c], s2 ? vj1 : vj0, D[c], false);
+                    }
                 }
                 if ((v * OB_DEC_WAVES + wave) * 512 < Kpad) {
 #pragma unroll
@@ -791,9 +800,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                         *reinterpret_cast<ob_u32x2 *>(dst + (size_t)(v * OB_DEC_WAVES + wave) * 2048 + c * 32) = (ob_u32x2){T[0][c], T[1][c]};
                 }
             }
-            // S of this wave, exact, digit (lane & 3) in every lane: a transposing reduction (4 values
-            // -> 2 -> 1 across lane ^ 2, lane ^ 1), rotate-adds inside the 16-lane rows, then the two
-            // gfx950 row swaps
+            // S of this wave, exact, digit (lane & 3) in every lane.  OB_SMFMA (default): S comes out of the matrix
+            // pipe itself -- eight more MFMAs per chunk and projection whose A operand is the all-ones word's masks
+            // (compile-time constants: no v_and), i.e. "every sign bit set": 128 * S_c lands in the accumulator layout,
+            // in the lanes that hold 128 * B_c.  The pipe has the room (48 of ~190 issue slots per wave); the VALU loses
+            // 8 v_dot4 per 8 elements and the 12-step transposing cross-lane reduction per projection.
+            // OB_SMFMA=0: v_dot4 per element + a transposing reduction (4 values -> 2 -> 1 across lane ^ 2, lane ^ 1),
+            // rotate-adds inside the 16-lane rows, then the two gfx950 row swaps
+            if (!SMF) {
             const bool hi2 = lane & 2, hi1 = lane & 1;
             int k0 = hi2 ? D[2] : D[0], k1 = hi2 ? D[3] : D[1];
             const int s0 = hi2 ? D[0] : D[2], s1 = hi2 ? D[1] : D[3];
@@ -808,6 +822,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             t = (int)(s16[0] + s16[1]);
             auto s32 = __builtin_amdgcn_permlane32_swap((uint32_t)t, (uint32_t)t, false, false);
             sdig[p] = (int)(s32[0] + s32[1]);
+            }
         }
         OB_STAMP(6);
         OB_ISSUE(C3, C4);
@@ -822,6 +837,21 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[j] = (ob_i32x4){0, 0, 0, 0};
         const char *bq = lds_q + (size_t)(gq * 16 + cpc) * 32;
+        // B operands (this wave's digit planes of one 512-weight chunk and projection: 8 x 16 bytes per lane) are
+        // read in BULK, 8 * NPROJ ds_read_b128 back to back behind one wait, and kept in registers: all MS slots
+        // of a projection multiply the same activations (with KV = 1 the chunk is the same for every group: one
+        // bulk read per launch), and the LDS serves a stream of independent reads at its full rate where it served
+        // read -> wait -> MFMA chains at a fraction of it (MI355X_MICROARCH.md, LDS: >= 16 DS operations per wait;
+        // the gate|up launch issued 48 dependent reads per wave for 16 distinct operands).  OB_BCACHE=0: the old form.
+#ifndef OB_BCACHE
+#define OB_BCACHE 1
+#endif
+        ob_i32x4 bc[NPROJ][8];
+        ob_i32x4 acc_s[NPROJ];
+#pragma unroll
+        for (int p = 0; p < NPROJ; ++p) acc_s[p] = (ob_i32x4){0, 0, 0, 0};
+        const ob_i32x4 ones_lo = {0x01010101, 0x02020202, 0x04040404, 0x08080808};
+        const ob_i32x4 ones_hi = {0x10101010, 0x20202020, 0x40404040, (int)0x80808080u};
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             {
@@ -832,27 +862,55 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             const int s = g / KV, ci = g % KV;
             if (ci < per_tile) {
                 const int ch = wave + ci * OB_DEC_WAVES;
+                if (OB_BCACHE && (KV > 1 || s == 0)) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                    for (int p = 0; p < NPROJ; ++p)
 #pragma unroll
-                    for (int jh = 0; jh < 2; ++jh) {
-                        ob_i32x4 bv[NPROJ];
+                        for (int qj = 0; qj < 8; ++qj)
+                            bc[p][qj] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + (qj >> 1) * 128 + (qj & 1) * 16);
+                }
+                // steps t = (q, jh) of the chunk, software-pipelined by one: the A operands (w & mask, 4 v_and per MFMA) of
+                // step t + 1 are formed BEFORE the MFMAs of step t are issued, in a second register set -- a v_and
+                // result feeding the very next instruction costs MFMA-hazard wait states and chains every MFMA behind
+                // its own operand preparation (hipcc reused ONE register quad for all 48 operands: 35 s_nop per wave)
+                auto masks = [&](int t, int p) -> ob_i32x4 {
+                    const uint32_t w = wreg[s * NPROJ + p][ci][t >> 1];
+                    ob_i32x4 av;
 #pragma unroll
-                        for (int p = 0; p < NPROJ; ++p)
-                            bv[p] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + q * 128 + jh * 16);
+                    for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * (t & 1) + v)));
+                    return av;
+                };
+                ob_i32x4 avn[NPROJ];
 #pragma unroll
-                        for (int p = 0; p < NPROJ; ++p) {
-                            const int j = s * NPROJ + p;
-                            const uint32_t w = wreg[j][ci][q];
-                            ob_i32x4 av;
+                for (int p = 0; p < NPROJ; ++p) avn[p] = masks(0, p);
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * jh + v)));
-                            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[p], acc[j], 0, 0, 0);
-                        }
-#ifdef OB_PROFILE_STAMPS
-                        if (g == 0 && q == 0 && jh == 0) OB_STAMP(7);
-#endif
+                for (int t = 0; t < 8; ++t) {
+                    ob_i32x4 avc[NPROJ], bv[NPROJ];
+#pragma unroll
+                    for (int p = 0; p < NPROJ; ++p) {
+                        avc[p] = avn[p];
+                        bv[p] = OB_BCACHE ? bc[p][t]
+                                          : *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + (t >> 1) * 128 + (t & 1) * 16);
                     }
+                    if (t < 7) {
+#pragma unroll
+                        for (int p = 0; p < NPROJ; ++p) avn[p] = masks(t + 1, p);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPROJ; ++p) {
+                        const int j = s * NPROJ + p;
+                        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[p], bv[p], acc[j], 0, 0, 0);
+                        if (SMF && s == 0)                  // 128 * S of this chunk: the all-ones word through the same step
+                            acc_s[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8((t & 1) ? ones_hi : ones_lo, bv[p], acc_s[p], 0, 0, 0);
+                    }
+#if OB_BCACHE
+                    if (t < 7) __builtin_amdgcn_sched_group_barrier(0x002, 4 * NPROJ, 0);                     // VALU: next step's masks
+                    if (SMF && s == 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPROJ, 0);         // MFMA: this step
+                    else __builtin_amdgcn_sched_group_barrier(0x008, NPROJ, 0);
+#endif
+#ifdef OB_PROFILE_STAMPS
+                    if (g == 0 && t == 0) OB_STAMP(7);
+#endif
                 }
             }
         }
@@ -869,7 +927,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             for (int p = 0; p < NPROJ; ++p) {
                 // a non-finite activation makes the whole output row NaN, as it does in the reference's GEMM
                 const float f = nonfinite[p] ? __builtin_nanf("") : dscale * inv_scale[p];
-                fa[p] = (float)sdig[p] * f;
+                fa[p] = (float)(SMF ? acc_s[p][0] : sdig[p]) * f;     // (all 16 rows of the ones operand are the same row)
                 fb[p] = -2.0f * f;
             }
 #pragma unroll

@@ -678,15 +678,24 @@ extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, c
     return ob_launch_status("rows_res_ln_rms");
 }
 
+extern "C" int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, const void *h_next, const float *row_stats, void *act,
+                                        int64_t T, int64_t I, float ln_eps, void *stream);
 extern "C" int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next, void *act, int64_t T, int64_t I,
                                   float ln_eps, void *stream)
+{
+    return onebit_rows_swiglu_stats(u_gate, u_up, h_next, nullptr, act, T, I, ln_eps, stream);
+}
+
+extern "C" int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, const void *h_next, const float *row_stats, void *act,
+                                        int64_t T, int64_t I, float ln_eps, void *stream)
 {
     if (T < 0 || I <= 0) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: bad size");
     if (I % 8 != 0 || I > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_swiglu: I = %lld", (long long)I);
     if (T == 0) return 0;
     if (!u_gate || !u_up || !act) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: null pointer");
     if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: dimension too large");
-    ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps, (const _Float16 *)h_next};
+    if (row_stats && !ob_aligned(row_stats, 16)) return ob_fail(ONEBIT_E_ALIGN, "rows_swiglu: row_stats must be 16-byte aligned");
+    ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps, (const _Float16 *)h_next, row_stats};
     hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
     return ob_launch_status("rows_swiglu");
 }
@@ -698,10 +707,23 @@ extern "C" int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int d
     return dtype == ONEBIT_F16 && T > 0 && K > 0 && N > 0 && K % 32 == 0 && ob_gemm3_ok(T, K, N) ? 1 : 0;
 }
 
+extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                                          const float *row_stats, void *q, void *k_cache, void *v_cache, int64_t B, int64_t S,
+                                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len,
+                                          int64_t max_pos, float ln_eps, unsigned flags, void *stream);
 extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
                                     void *q, void *k_cache, void *v_cache, int64_t B, int64_t S, int32_t n_heads,
                                     int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len, int64_t max_pos,
                                     float ln_eps, unsigned flags, void *stream)
+{
+    return onebit_rows_qkv_rope_stats(u_q, u_k, u_v, cos, sin, nullptr, q, k_cache, v_cache, B, S, n_heads, n_kv_heads, head_dim,
+                                      past_len, max_len, max_pos, ln_eps, flags, stream);
+}
+
+extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                                          const float *row_stats, void *q, void *k_cache, void *v_cache, int64_t B, int64_t S,
+                                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len,
+                                          int64_t max_pos, float ln_eps, unsigned flags, void *stream)
 {
     if (flags & ~ONEBIT_FLAG_Q_TOKEN_MAJOR) return ob_fail(ONEBIT_E_FLAG, "rows_qkv_rope: unknown flags 0x%x", flags);
     if (B < 0 || S < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || past_len < 0)
@@ -717,7 +739,7 @@ extern "C" int onebit_rows_qkv_rope(const void *u_q, const void *u_k, const void
     if (B * S > 0x7fffffffLL || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope: dimension too large");
     ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
                        (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, (int)S, n_heads, n_kv_heads, head_dim, (int)past_len,
-                       (int)max_len, (flags & ONEBIT_FLAG_Q_TOKEN_MAJOR) ? 1 : 0, ln_eps};
+                       (int)max_len, (flags & ONEBIT_FLAG_Q_TOKEN_MAJOR) ? 1 : 0, ln_eps, row_stats};
     hipLaunchKernelGGL(ob_qkv_rope_kernel, dim3((unsigned)(B * S)), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
     return ob_launch_status("rows_qkv_rope");
 }

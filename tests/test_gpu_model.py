@@ -147,6 +147,58 @@ def test_tensor_parallel_prefill_world1_matches_module_path():
     assert tp.kv[0][0].shape == (3, 4, 37, cfg.head_dim)
 
 
+def test_fused_tensor_parallel_prefill_world1_and_stats_kernels(golden_dir):
+    """The fused tensor-parallel route (tp.py with HipGlue: onebit_rows_qkv_rope_stats / onebit_rows_swiglu_stats with the
+    statistics GIVEN, onebit_rows_res_ln_rms on the reduce-scattered rows) at degree 1: against the module path on a
+    GQA model, against the REFERENCE's recorded logits on the tiny golden model, and the two *_stats kernels against
+    their self-computing forms fed the same statistics."""
+    import ctypes
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.tp import TensorParallelPrefill
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=512, hidden_size=512, intermediate_size=1408, num_hidden_layers=3,
+                            num_attention_heads=8, num_key_value_heads=4, max_position_embeddings=128)
+    model = build_synthetic_model(cfg, seed=6, device=dev)
+    ids = torch.randint(0, 512, (3, 37), generator=torch.Generator().manual_seed(2)).to(dev)
+    ref = model(ids)
+    tp = TensorParallelPrefill(model, 0, 1, attention="sdpa")
+    assert tp.fused
+    got = tp(ids)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 6e-3 * scale
+    assert tp.exchanges == 2 * cfg.num_hidden_layers and tp.kv[0][0].shape == (3, 4, 37, cfg.head_dim)
+    assert not TensorParallelPrefill(model, 0, 1).fused              # attention="eager": torch glue, reference op order
+    # the reference's own logits (tiny golden model b: every projection on the MFMA path)
+    z = np.load(os.path.join(golden_dir, "model_tiny_b.npz"))
+    from onebit_amd.llama import OneBitLlamaForCausalLM
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    gm = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
+    gm.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")})
+    gm = gm.to(dev).eval()
+    lg = TensorParallelPrefill(gm, 0, 1, attention="sdpa")(torch.from_numpy(z["input_ids"]).to(dev)).cpu().numpy()
+    ref16, ref32 = z["prefill_logits_f16"], z["prefill_logits_f32"]
+    assert np.abs(lg - ref16).max() <= max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
+    # *_stats kernels == the self-computing kernels when given the statistics those compute (fp32 two-pass here: the
+    # outputs may differ by an fp16 ulp where mean / rstd differ in the last fp32 bits)
+    lib, sp = _lib.load(), _stream_ptr(dev)
+    T, I = 19, 1408
+    g = torch.Generator().manual_seed(4)
+    ug = (0.4 * torch.randn(T, I, generator=g) + 0.1).half().to(dev)
+    uu = (0.6 * torch.randn(T, I, generator=g)).half().to(dev)
+    def mr(u):
+        f = u.float()
+        m = f.mean(-1)
+        return m, torch.rsqrt(((f - m[:, None]) ** 2).mean(-1) + 1e-5)
+    st4 = torch.stack([*mr(ug), *mr(uu)], dim=-1).contiguous()
+    a0, a1 = torch.empty_like(ug), torch.empty_like(ug)
+    _lib.check(lib.onebit_rows_swiglu(ug.data_ptr(), uu.data_ptr(), None, a0.data_ptr(), T, I, 1e-5, sp), "swiglu")
+    _lib.check(lib.onebit_rows_swiglu_stats(ug.data_ptr(), uu.data_ptr(), None, st4.data_ptr(), a1.data_ptr(), T, I, 1e-5, sp), "swiglu_stats")
+    d = (a0.float() - a1.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * max(1.0, float(a0.float().abs().max())) and float((d > 0).float().mean()) <= 0.02
+
+
 def test_rows_qkv_rope_matches_module_ops():
     """onebit_rows_qkv_rope (LayerNorm of the q|k|v rows + RoPE + head transpose, k / v into cache rows at
     past_len) against the module path's torch ops (F.layer_norm, the rotate_half formula of

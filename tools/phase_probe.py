@@ -1,5 +1,5 @@
-"""In-kernel phase timeline of the fused decode GEMV launches (profiling build: -DOB_PROFILE_ABLATE,
-OB_TIMING=1).  Stamps are kept in registers and written at kernel end.  Usage:
+"""In-kernel phase timeline of the fused decode GEMV launches (stamps-only profiling build -DOB_PROFILE_STAMPS: the
+ablation build's early-return branches put vmcnt(0) behind every weight load and stretch the head).  Stamps are kept in registers and written at kernel end.  Usage:
   [OB_EXTRA="-DOB_STRIDED_LOADS"] [OB_PROBE_STATS=0|1] python tools/phase_probe.py"""
 import ctypes, os, sys, subprocess
 import numpy as np, torch
@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 so = os.environ.get("OB_LIB") or "/tmp/libonebit_prof_%d.so" % os.getpid()
 if not os.environ.get("OB_LIB"):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-                       "-Wno-unused-value", "-DOB_PROFILE_ABLATE", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
+                       "-Wno-unused-value", "-DOB_PROFILE_STAMPS", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
                        os.path.join(ROOT, "onebit_amd/csrc/onebit_hip.hip")])
 from onebit_amd import _lib
 _lib.LIB_PATH = so
@@ -36,7 +36,7 @@ def run(kind, l):
     else: fused_gemv([l.mlp.down_proj], [od], PRO_SWIGLU, u_gate=ug, u_up=uu, stats_out=so_(stH2), **si(st_gate=stI, st_up=stI2))
 lib.onebit_debug_read_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ["entry", "loads issued", "LN stats ready", "RMS reduced", "x ready", "amax", "digits in LDS / flag seen", "first MFMA group", "MFMA done", "after partials barrier", "end"]
-print("build:", os.environ.get("OB_LIB", os.environ.get("OB_EXTRA", "(default)")), " stats:", USE_STATS, " OB_DEC2:", os.environ.get("OB_DEC2", "1"))
+print("build:", os.environ.get("OB_LIB", os.environ.get("OB_EXTRA", "(default)")), " stats:", USE_STATS, " OB_DEC2:", os.environ.get("OB_DEC2", "0"))
 layers = list(model.model.layers)
 def report(tag, a):
     with np.errstate(all="ignore"):
@@ -62,7 +62,7 @@ for kind in ("o", "qkv", "gateup", "down"):
     with np.errstate(all="ignore"):
         a = np.nanmedian(np.stack(acc), axis=0)       # [256 wg][16 waves][11]
     print(kind, "-- cycles since the wave entered (min / median / max over the grid's waves)")
-    dec2 = int(os.environ.get("OB_DEC2", "1"))
+    dec2 = int(os.environ.get("OB_DEC2", "0"))
     if not (dec2 == 2 or (dec2 == 1 and kind != "o")):   # single-role kernel: dbg holds [wg][8 waves][16]
         b = buf.reshape(-1)[: 256 * 8 * 16].reshape(256, 8, 16).astype(np.float64)
         b[b == 0] = np.nan
