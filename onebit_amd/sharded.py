@@ -219,9 +219,10 @@ def shard_n(weight: torch.Tensor, input_factor: torch.Tensor, weight_scale: torc
                   None if bias is None else bias[n0:n1].contiguous(), n0, n1, KB * 8, N)
 
 
-def hip_rows_u(shard: NShard, x: torch.Tensor) -> torch.Tensor:
+def hip_rows_u(shard: NShard, x: torch.Tensor, prescaled: bool = False) -> torch.Tensor:
     """Pre-LayerNorm u = fp16(fp16(z) * g) of this rank's rows, [T, n1-n0], through the C ABI
-    (onebit_linear_forward with ONEBIT_FLAG_SKIP_LN on the row slice)."""
+    (onebit_linear_forward with ONEBIT_FLAG_SKIP_LN on the row slice).  ``prescaled``: x already holds
+    fp16(x * input_factor) (ONEBIT_FLAG_PRESCALED; only where ``hip_prescaled_ok``)."""
     from . import _lib
     from .bitnet import _dtype_code, _stream_ptr
     lib = _lib.load()
@@ -229,17 +230,30 @@ def hip_rows_u(shard: NShard, x: torch.Tensor) -> torch.Tensor:
     n = shard.n1 - shard.n0
     code = _dtype_code(x.dtype)
     u = torch.empty((T, n), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
-        ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
+    ws_bytes = 0
+    if not prescaled:
+        with torch.cuda.device(x.device):
+            ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     w = shard.weight
     with torch.cuda.device(x.device):
         rc = lib.onebit_linear_forward(w.data_ptr(), w.stride(0), x.data_ptr(), shard.input_factor.data_ptr(),
                                        shard.weight_scale.data_ptr(), None, u.data_ptr(), None,
                                        None if ws is None else ws.data_ptr(), ws_bytes, T, K, n, code, 0.0,
-                                       _lib.FLAG_SKIP_LN, _stream_ptr(x.device))
+                                       _lib.FLAG_SKIP_LN | (_lib.FLAG_PRESCALED if prescaled else 0), _stream_ptr(x.device))
     _lib.check(rc, "onebit_linear_forward")
     return u
+
+
+def hip_prescaled_ok(shard, T: int, device) -> bool:
+    """True when a T-row fp16 call on this shard's matrix may take pre-scaled rows (the LDS-DMA GEMM)."""
+    from . import _lib
+    w = shard.weight
+    n = w.shape[0]
+    if shard.bias is not None or w.stride(-1) != 1 or w.stride(0) % 16 or w.data_ptr() % 16 or shard.weight_scale.dtype != torch.float16:
+        return False
+    with torch.cuda.device(device):
+        return bool(_lib.load().onebit_linear_prescaled_ok(T, w.shape[1] * 8, n, _lib.ONEBIT_F16))
 
 
 def hip_row_stats(u: torch.Tensor) -> torch.Tensor:

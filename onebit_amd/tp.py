@@ -82,14 +82,15 @@ class HipGlue:
         return q, k, v
 
     @staticmethod
-    def swiglu(u_g, u_u, stats4, eps):
+    def swiglu(u_g, u_u, stats4, eps, h_next=None):
         from . import _lib
         from .bitnet import _stream_ptr
         lib = _lib.load()
         act = torch.empty_like(u_g)
         st = stats4.contiguous()
         with torch.cuda.device(u_g.device):
-            rc = lib.onebit_rows_swiglu_stats(u_g.data_ptr(), u_u.data_ptr(), None, st.data_ptr(), act.data_ptr(), u_g.shape[0],
+            rc = lib.onebit_rows_swiglu_stats(u_g.data_ptr(), u_u.data_ptr(), None if h_next is None else h_next.data_ptr(),
+                                              st.data_ptr(), act.data_ptr(), u_g.shape[0],
                                               u_g.shape[1], eps, _stream_ptr(u_g.device))
         _lib.check(rc, "onebit_rows_swiglu_stats")
         return act
@@ -109,19 +110,23 @@ class HipGlue:
         return u
 
     @staticmethod
-    def res_ln_rms(h, u, w, rms_eps, ln_eps):
-        """h + LayerNorm(u) -> new residual rows; RMSNorm(that) * w -> x."""
+    def res_ln_rms(h, u, w, rms_eps, ln_eps, h_next=()):
+        """h + LayerNorm(u) -> new residual rows; RMSNorm(that) * w -> x.  ``h_next`` (<= 3 input_factor vectors): also
+        the consumers' pre-scaled rows fp16(x * h_i) (returned as a list; x itself is then not written)."""
         import ctypes
         from . import _lib
         from .bitnet import _stream_ptr
         lib = _lib.load()
-        hout, x = torch.empty_like(h), torch.empty_like(h)
-        nul = (ctypes.c_void_p * 3)()
+        hout = torch.empty_like(h)
+        x = None if h_next else torch.empty_like(h)
+        xs = [torch.empty_like(h) for _ in h_next]
+        hp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in h_next])
+        xp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in xs])
         with torch.cuda.device(h.device):
-            rc = lib.onebit_rows_res_ln_rms(h.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(), x.data_ptr(), nul, nul, 0,
-                                            h.shape[0], h.shape[1], rms_eps, ln_eps, _stream_ptr(h.device))
+            rc = lib.onebit_rows_res_ln_rms(h.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(), None if x is None else x.data_ptr(),
+                                            hp, xp, len(xs), h.shape[0], h.shape[1], rms_eps, ln_eps, _stream_ptr(h.device))
         _lib.check(rc, "onebit_rows_res_ln_rms")
-        return hout, x
+        return (hout, x) if not h_next else (hout, xs)
 
     @staticmethod
     def attention(q, k, v):
@@ -349,28 +354,61 @@ class TensorParallelPrefill:
         x = pad(layers[0].input_layernorm(emb)) if len(layers) else None
         x_own = None
         self.kv, self.exchanges = [], 0
+        # Degree 1 with the HIP kernels: nothing is exchanged, so the producers can hand the consumers their pre-scaled rows
+        # fp16(x * input_factor) directly (ONEBIT_FLAG_PRESCALED, as the single-GPU fused route does) and a K-"shard" is the
+        # whole layer: its fp16 pre-LayerNorm rows come straight from the GEMM instead of fp32 partials + a rounding pass.
+        # With n > 1 the gathered x is shared by consumers with different input_factors and the partial sums cross ranks.
+        direct = n == 1 and G is HipGlue and rows_fn is sharded.hip_rows_u and self.partial_fn is sharded.hip_partial
+        pre = lambda shards: direct and all(sharded.hip_prescaled_ok(s_, Tp, dev) for s_ in shards)
+        xs = None                                   # pre-scaled copies of x for the next consumers, when available
+
+        def k_rows(shard, a, a_scaled):
+            """u (fp16, own rows) of a K-sharded layer: partial sums -> reduce_scatter -> fp16(fp16(z) * g); degree 1: direct."""
+            if direct:
+                full = NShard(shard.weight, shard.input_factor, shard.weight_scale, None, 0, shard.out_features,
+                              shard.k1 - shard.k0, shard.out_features)
+                return rows_fn(full, a, prescaled=True) if a_scaled else rows_fn(full, a)
+            return G.u_rows(shard, self._reduce_scatter_rows(self.partial_fn(shard, a), rows), dt)
+
         for li, (layer, sh) in enumerate(zip(layers, self.layers)):
             # --- q | k | v of the local heads for all tokens; LayerNorm over the COMPLETE rows via combined statistics
-            u_q, u_k, u_v = rows_fn(sh.q, x), rows_fn(sh.k, x), rows_fn(sh.v, x)
+            if xs is not None:
+                u_q, u_k, u_v = (rows_fn(s_, a_, prescaled=True) for s_, a_ in zip((sh.q, sh.k, sh.v), xs))
+            else:
+                u_q, u_k, u_v = rows_fn(sh.q, x), rows_fn(sh.k, x), rows_fn(sh.v, x)
             st6 = self._complete_stats([stats_fn(u_q), stats_fn(u_k), stats_fn(u_v)], [sh.q, sh.k, sh.v], 1e-5)
             q, k, v = G.qkv_rope(u_q[:T], u_k[:T], u_v[:T], st6[:T], cos, sin, B, S, Hl, Hkvl, D, 1e-5)
             self.kv.append((k, v))
             o = pad(G.attention(q, k, v))
             # --- o_proj on the local heads' columns -> ONE reduction -> u on own rows -> LayerNorm + residual + RMSNorm fused
-            zo = self._reduce_scatter_rows(self.partial_fn(sh.o, o), rows)
-            h_own, x2_own = G.res_ln_rms(h_own, G.u_rows(sh.o, zo, dt), layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5)
-            x2 = self._all_gather_rows(x2_own)
+            u_o = k_rows(sh.o, o, False)
+            if pre((sh.gate, sh.up)):
+                h_own, (ag, au) = G.res_ln_rms(h_own, u_o, layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5,
+                                               h_next=(sh.gate.input_factor, sh.up.input_factor))
+                u_g, u_u = rows_fn(sh.gate, ag, prescaled=True), rows_fn(sh.up, au, prescaled=True)
+            else:
+                h_own, x2_own = G.res_ln_rms(h_own, u_o, layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5)
+                x2 = self._all_gather_rows(x2_own)
+                u_g, u_u = rows_fn(sh.gate, x2), rows_fn(sh.up, x2)
             self.exchanges += 1
             # --- MLP
-            u_g, u_u = rows_fn(sh.gate, x2), rows_fn(sh.up, x2)
             st4 = self._complete_stats([stats_fn(u_g), stats_fn(u_u)], [sh.gate, sh.up], 1e-5)
-            act = G.swiglu(u_g, u_u, st4, 1e-5)
-            zd = self._reduce_scatter_rows(self.partial_fn(sh.down, act), rows)
-            nxt = layers[li + 1].input_layernorm.weight if li + 1 < len(layers) else model.model.norm.weight
-            h_own, x_own = G.res_ln_rms(h_own, G.u_rows(sh.down, zd, dt), nxt, cfg.rms_norm_eps, 1e-5)
+            down_pre = direct and sharded.hip_prescaled_ok(NShard(sh.down.weight, sh.down.input_factor, sh.down.weight_scale, None, 0,
+                                                                  sh.down.out_features, sh.down.k1 - sh.down.k0, sh.down.out_features), Tp, dev)
+            act = G.swiglu(u_g, u_u, st4, 1e-5, sh.down.input_factor) if down_pre else G.swiglu(u_g, u_u, st4, 1e-5)
+            u_d = k_rows(sh.down, act, down_pre)
+            last = li + 1 >= len(layers)
+            nxt = model.model.norm.weight if last else layers[li + 1].input_layernorm.weight
+            nsh = None if last else self.layers[li + 1]
+            if nsh is not None and pre((nsh.q, nsh.k, nsh.v)):
+                h_own, xs = G.res_ln_rms(h_own, u_d, nxt, cfg.rms_norm_eps, 1e-5,
+                                         h_next=(nsh.q.input_factor, nsh.k.input_factor, nsh.v.input_factor))
+            else:
+                xs = None
+                h_own, x_own = G.res_ln_rms(h_own, u_d, nxt, cfg.rms_norm_eps, 1e-5)
+                if not last:
+                    x = self._all_gather_rows(x_own)
             self.exchanges += 1
-            if li + 1 < len(layers):
-                x = self._all_gather_rows(x_own)
         if x_own is None:                                                       # a model without layers
             x_own = model.model.norm(h_own)
         own_logits = model.lm_head(x_own).float()
