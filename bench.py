@@ -337,21 +337,26 @@ def measure_prefill_model(model, dev, B=8, S=2048):
     cfg = model.config
     S = min(S, cfg.max_position_embeddings)
     ids = torch.randint(0, cfg.vocab_size, (B, S), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev)
-    model.set_attention("sdpa").set_fused_glue(True)
-    try:
-        with torch.no_grad():
-            model(ids[:1, :128])
-            dt, dmin = _timed(lambda: model(ids), dev, 1, warm=2, iters=20)
-    finally:
-        model.set_attention("eager").set_fused_glue(False)
-        torch.cuda.empty_cache()
+    res = {}
+    for impl in ("hip", "sdpa"):
+        model.set_attention(impl).set_fused_glue(True)
+        try:
+            with torch.no_grad():
+                model(ids[:1, :128])
+                res[impl] = _timed(lambda: model(ids), dev, 1, warm=2, iters=20 if impl == "hip" else 6)
+        finally:
+            model.set_attention("eager").set_fused_glue(False)
+            torch.cuda.empty_cache()
+    dt, dmin = res["hip"]
     H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     w1 = L * (4 * H * H + 3 * H * I)
     return {"batch": B, "seq_len": S, "ms": round(dt * 1e3, 1), "ms_min": round(dmin * 1e3, 1), "iterations": 20,
             "tokens_per_s": round(B * S / dt, 1),
             "onebit_layer_TFLOPs_equivalent": round(2.0 * B * S * w1 / dt / 1e12, 1),
-            "attention": "torch SDPA (AOTriton kernel)", "glue": "onebit_rows_res_ln_rms (writes the consumers' pre-scaled rows) + onebit_rows_qkv_rope + "
-                                         "onebit_rows_swiglu; projections with ONEBIT_FLAG_PRESCALED", "per": "GPU"}
+            "attention": "onebit_attention_prefill (own causal flash kernel on MFMA, writes o_proj's pre-scaled rows)",
+            "ms_with_torch_sdpa_attention": round(res["sdpa"][0] * 1e3, 1),
+            "glue": "onebit_rows_res_ln_rms (writes the consumers' pre-scaled rows) + onebit_rows_qkv_rope + "
+                    "onebit_rows_swiglu; projections with ONEBIT_FLAG_PRESCALED", "per": "GPU"}
 
 
 def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048, tp_kwargs=None, timed=None):
@@ -365,7 +370,7 @@ def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048, tp_kwargs=Non
     ids = torch.randint(0, cfg.vocab_size, (B, S), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev)
     # (tp_kwargs / timed: the world-2 gloo test runs THIS function on CPU with stand-in compute callbacks and a wall-clock
     # timer, so the control flow the driver launches on N GPUs has executed with more than one rank)
-    tp = TensorParallelPrefill(model, rank, world, **(tp_kwargs or dict(attention="sdpa")))
+    tp = TensorParallelPrefill(model, rank, world, **(tp_kwargs or dict(attention="hip")))
     timed = timed or _timed
     try:
         tp(ids[:1, :min(128, S)], gather_logits=False)
@@ -382,7 +387,7 @@ def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048, tp_kwargs=Non
             "tokens_per_s": round(T / dt, 1), "onebit_layer_TFLOPs_equivalent": round(2.0 * T * w1 / dt / 1e12, 1),
             "exchanges_per_layer": 2 if world > 1 else 0,
             "bytes_per_exchange_per_rank": (T * H * 4 + T * H * 2) if world > 1 else 0,
-            "attention": "torch SDPA (AOTriton kernel) on the local heads", "logits": "own token rows only (not gathered)",
+            "attention": "onebit_attention_prefill on the local heads", "logits": "own token rows only (not gathered)",
             "glue": "fused row kernels (onebit_rows_qkv_rope_stats / onebit_rows_res_ln_rms / onebit_rows_swiglu_stats)" if tp_fused else "torch ops"}
 
 

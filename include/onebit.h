@@ -174,6 +174,18 @@ int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v
                                int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t past_len, int64_t max_len,
                                int64_t max_pos, float ln_eps, unsigned flags, void *stream);
 
+/* Causal prefill attention on the rows onebit_rows_qkv_rope wrote (modeling_bitllama.py:546-563: q k^T / sqrt(D), causal
+ * mask, fp32 softmax, . v), flash style on MFMA: no [S, S] tensor in HBM.  fp16.
+ *   q [B, S, n_heads, D] token-major (ONEBIT_FLAG_Q_TOKEN_MAJOR), k / v cache rows [B][n_kv_heads][max_len][D] of which
+ *   positions 0 .. past_len + S - 1 are valid (query s sits at position past_len + s), o [B, S, n_heads, D] token-major =
+ *   the rows o_proj consumes.  h_next (optional, [n_heads * D]): o <- fp16(o * h_next), o_proj's input scaling
+ *   (bitnet.py:113) so that it can be called with ONEBIT_FLAG_PRESCALED.  head_dim 64 or 128.
+ * Differs from the reference's eager op order as its own flash-attention switch does (LlamaFlashAttention2,
+ * modeling_bitllama.py:588): scores and probabilities are not rounded to fp16 tensors on the way. */
+int onebit_attention_prefill(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next_or_null,
+                             int64_t B, int64_t S, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                             int64_t past_len, int64_t max_len, void *stream);
+
 /* ---- whole-token greedy decode, batch 1 ---------------------
  * One call enqueues every kernel of one decoded token of the reference's
  * BitLlamaForCausalLMInf (modeling_bitllama.py:1512; decoder layer :856-928, attention

@@ -42,6 +42,7 @@ SYMBOLS = {
     "onebit_rows_swiglu_stats": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
     "onebit_rows_qkv_rope_stats": (_int, [_vp] * 9 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
+    "onebit_attention_prefill": (_int, [_vp] * 5 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _vp]),
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),
     "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),

@@ -16,6 +16,7 @@
 #include "ob_skinny.h"
 #include "ob_batch.h"
 #include "ob_train.h"
+#include "ob_flash.h"
 
 static thread_local char g_err[256] = "";
 
@@ -1249,4 +1250,28 @@ extern "C" int onebit_train_backward(const void *gy, const void *x, const void *
     hipStream_t s = (hipStream_t)stream;
     return dtype == ONEBIT_F16 ? ob_train_backward_t<_Float16>(gy, x, w_latent, h, g, z_save, ln_stats, gx, gw, gh, gg, gbias_or_null, (char *)workspace, T, K, N, s)
                                : ob_train_backward_t<float>(gy, x, w_latent, h, g, z_save, ln_stats, gx, gw, gh, gg, gbias_or_null, (char *)workspace, T, K, N, s);
+}
+
+// ------------------------------------------------------------ prefill attention --
+extern "C" int onebit_attention_prefill(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next,
+                                        int64_t B, int64_t S, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                                        int64_t past_len, int64_t max_len, void *stream)
+{
+    if (B < 0 || S < 0 || n_heads <= 0 || n_kv_heads <= 0 || past_len < 0) return ob_fail(ONEBIT_E_ARG, "attention_prefill: bad size");
+    if ((head_dim != 64 && head_dim != 128) || n_heads % n_kv_heads != 0)
+        return ob_fail(ONEBIT_E_SHAPE, "attention_prefill: head_dim %d (64 or 128), heads %d / %d", head_dim, n_heads, n_kv_heads);
+    if (past_len + S > max_len) return ob_fail(ONEBIT_E_SHAPE, "attention_prefill: %lld + %lld tokens beyond the cache (%lld)",
+                                               (long long)past_len, (long long)S, (long long)max_len);
+    if (B == 0 || S == 0) return 0;
+    if (!q || !k_cache || !v_cache || !o) return ob_fail(ONEBIT_E_ARG, "attention_prefill: null pointer");
+    if (!ob_aligned(q, 16) || !ob_aligned(k_cache, 16) || !ob_aligned(v_cache, 16) || !ob_aligned(o, 8) || (h_next && !ob_aligned(h_next, 8)))
+        return ob_fail(ONEBIT_E_ALIGN, "attention_prefill: q / k / v must be 16-byte aligned");
+    const int64_t nmb = (S + OB_FL_BM - 1) / OB_FL_BM;
+    if (nmb * n_heads * B > 0x7fffffffLL || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "attention_prefill: dimension too large");
+    ObFlashArgs a = {(const _Float16 *)q, (const _Float16 *)k_cache, (const _Float16 *)v_cache, (_Float16 *)o, (const _Float16 *)h_next,
+                     (int)S, n_heads, n_kv_heads, (int)max_len, (int)past_len, 1.4426950408889634f / sqrtf((float)head_dim), (int)nmb};
+    const dim3 grid((unsigned)(nmb * n_heads * B));
+    if (head_dim == 128) hipLaunchKernelGGL((ob_flash_fwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ob_flash_fwd_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    return ob_launch_status("attention_prefill");
 }

@@ -107,6 +107,24 @@ class LlamaMLPInf(nn.Module):
         return self.down_proj(nn.functional.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
+def hip_attention_prefill(q: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, past_len: int, h_next: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal attention of S new tokens against cache rows 0 .. past_len + S - 1 through ``onebit_attention_prefill``.
+    q [B, S, H, D] fp16 contiguous (token-major), kc / vc [slots >= B, Hkv, max_len, D] contiguous with the new tokens'
+    keys / values already written; returns [B, S, H, D] (optionally times ``h_next`` [H * D], rounded once more)."""
+    from . import _lib
+    from .bitnet import _stream_ptr
+    B, S, H, D = q.shape
+    if kc.shape[0] < B or kc.shape[3] != D or kc.shape != vc.shape or kc.dtype != q.dtype or not q.is_contiguous():
+        raise ValueError("hip_attention_prefill: cache / query geometry mismatch")
+    o = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        rc = _lib.load().onebit_attention_prefill(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(),
+                                                  None if h_next is None else h_next.data_ptr(), B, S, H, kc.shape[1], D, past_len,
+                                                  kc.shape[2], _stream_ptr(q.device))
+    _lib.check(rc, "onebit_attention_prefill")
+    return o
+
+
 class LlamaAttentionInf(nn.Module):
     """modeling_bitllama.py:431-585, eager attention, preallocated KV cache."""
 
@@ -143,6 +161,11 @@ class LlamaAttentionInf(nn.Module):
             rep = H // Hkv
             keys = keys.repeat_interleave(rep, dim=1)
             vals = vals.repeat_interleave(rep, dim=1)
+        if self.attn_impl == "hip" and S > 1 and q.dtype == torch.float16 and D in (64, 128) and kc.is_contiguous() and vc.is_contiguous():
+            # the build's own fused causal attention (onebit_attention_prefill: flash style on MFMA, csrc/ob_flash.h),
+            # any past_len; q goes in token-major, the output comes back as the [B, S, H * D] rows o_proj consumes
+            o = hip_attention_prefill(q.transpose(1, 2).contiguous(), kc, vc, past_len)
+            return o_proj(o.view(B, S, H * D))
         if self.attn_impl == "sdpa" and S > 1 and past_len == 0:
             # fused causal attention (the reference offers the same switch: LlamaFlashAttention2 under
             # config._flash_attn_2_enabled, modeling_bitllama.py:588,862): no [S, S] score tensor in HBM.
@@ -218,9 +241,10 @@ class OneBitLlamaForCausalLM(nn.Module):
         return self._rope
 
     def set_attention(self, impl: str) -> "OneBitLlamaForCausalLM":
-        """"eager" (reference op order, default) or "sdpa" (fused prefill attention)."""
-        if impl not in ("eager", "sdpa"):
-            raise ValueError("attention implementation must be 'eager' or 'sdpa'")
+        """"eager" (reference op order, default), "hip" (this build's fused causal prefill attention kernel,
+        ``onebit_attention_prefill``) or "sdpa" (torch's fused attention -- an AOTriton kernel on ROCm; kept for A/B)."""
+        if impl not in ("eager", "sdpa", "hip"):
+            raise ValueError("attention implementation must be 'eager', 'hip' or 'sdpa'")
         for layer in self.model.layers:
             layer.self_attn.attn_impl = impl
         return self
@@ -273,7 +297,9 @@ class OneBitLlamaForCausalLM(nn.Module):
         u_down = None
         for li, (layer, kv) in enumerate(zip(m.layers, cache.layers)):
             att = layer.self_attn
-            fused_attn = (att.attn_impl == "sdpa" and S > 1 and past == 0 and att.q_proj.bias is None and att.k_proj.bias is None
+            fused_attn = (att.attn_impl in ("sdpa", "hip") and S > 1 and (past == 0 or att.attn_impl == "hip")
+                          and (att.attn_impl == "sdpa" or att.head_dim in (64, 128))
+                          and att.q_proj.bias is None and att.k_proj.bias is None
                           and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()
                           and att.head_dim >= 16 and att.head_dim & (att.head_dim - 1) == 0
                           # onebit_rows_qkv_rope writes rows [b < B][kv head][past + s][D] through raw pointers: the
@@ -282,7 +308,7 @@ class OneBitLlamaForCausalLM(nn.Module):
                           and all(c.dim() == 4 and c.shape[0] >= B and c.dtype == h.dtype and c.device == h.device
                                   and tuple(c.shape[1:]) == (att.num_key_value_heads, kv[0].shape[2], att.head_dim)
                                   for c in kv)
-                          and S <= kv[0].shape[2])
+                          and past + S <= kv[0].shape[2])
             if u_down is not None:
                 h, x, xs = res_ln_rms(h, u_down, layer.input_layernorm.weight,
                                       (att.q_proj, att.k_proj, att.v_proj) if fused_attn else ())
@@ -298,11 +324,18 @@ class OneBitLlamaForCausalLM(nn.Module):
                     _lib.check(lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                                                         q.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past,
                                                         kc.shape[2], cos.shape[0], 1e-5, _lib.FLAG_Q_TOKEN_MAJOR, sp), "onebit_rows_qkv_rope")
-                keys, vals = kc[:B, :, :S], vc[:B, :, :S]
-                if Hkv != Hh:
-                    keys, vals = keys.repeat_interleave(Hh // Hkv, dim=1), vals.repeat_interleave(Hh // Hkv, dim=1)
-                o = nn.functional.scaled_dot_product_attention(q.transpose(1, 2), keys, vals, is_causal=True)
-                u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))    # (no copy when o is token-major)
+                if att.attn_impl == "hip":
+                    # own flash kernel: rows come back token-major, already multiplied by o_proj's input_factor when o_proj
+                    # takes pre-scaled rows at this T (no separate scaling pass left on the route)
+                    o_pres = att.o_proj.prescaled_ok(T, h.dtype)
+                    o = hip_attention_prefill(q, kc, vc, past, att.o_proj.input_factor if o_pres else None).view(T, Hh * D)
+                    u_o = att.o_proj.pre_layernorm_prescaled(o) if o_pres else att.o_proj.pre_layernorm(o)
+                else:
+                    keys, vals = kc[:B, :, :S], vc[:B, :, :S]
+                    if Hkv != Hh:
+                        keys, vals = keys.repeat_interleave(Hh // Hkv, dim=1), vals.repeat_interleave(Hh // Hkv, dim=1)
+                    o = nn.functional.scaled_dot_product_attention(q.transpose(1, 2), keys, vals, is_causal=True)
+                    u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))    # (no copy when o is token-major)
             else:
                 u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
             mlp = layer.mlp

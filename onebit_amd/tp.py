@@ -129,9 +129,16 @@ class HipGlue:
         return (hout, x) if not h_next else (hout, xs)
 
     @staticmethod
-    def attention(q, k, v):
-        """Causal attention on the local heads: q [B, S, Hl, D] token-major, k / v [B, Hkvl, S, D] -> [B * S, Hl * D]."""
+    def attention(q, k, v, impl="hip", h_next=None):
+        """Causal attention on the local heads: q [B, S, Hl, D] token-major, k / v [B, Hkvl, S, D] -> [B * S, Hl * D].
+        ``impl="hip"``: the build's own flash kernel (onebit_attention_prefill; with ``h_next`` the rows come back already
+        multiplied by o_proj's input_factor slice); "sdpa": torch's fused attention."""
         B, S, Hl, D = q.shape
+        if impl == "hip" and D in (64, 128) and q.dtype == torch.float16:
+            from .llama import hip_attention_prefill
+            return hip_attention_prefill(q, k, v, 0, h_next).view(B * S, Hl * D)
+        if h_next is not None:
+            raise ValueError("pre-scaled attention rows need the hip attention kernel")
         if k.shape[1] != Hl:
             k, v = k.repeat_interleave(Hl // k.shape[1], dim=1), v.repeat_interleave(Hl // v.shape[1], dim=1)
         o = nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k, v, is_causal=True)
@@ -208,7 +215,7 @@ class TensorParallelPrefill:
             raise ValueError("fused tensor-parallel glue needs an fp16 model without projection biases and a power-of-two head_dim")
         # default: fused whenever it is possible AND the caller asked for the fused attention (attention="eager" keeps the
         # reference's op order end to end, torch glue included)
-        self.fused = (can_fuse and (attention == "sdpa" or glue is not None)) if fused is None else bool(fused)
+        self.fused = (can_fuse and (attention in ("sdpa", "hip") or glue is not None)) if fused is None else bool(fused)
         self.glue = glue if glue is not None else HipGlue
         self.plan = TPPlan.make(self.cfg, rank, world)
         self.fns = dict(rows_fn=rows_fn, stats_fn=stats_fn, normalize_fn=normalize_fn)
@@ -379,9 +386,16 @@ class TensorParallelPrefill:
             st6 = self._complete_stats([stats_fn(u_q), stats_fn(u_k), stats_fn(u_v)], [sh.q, sh.k, sh.v], 1e-5)
             q, k, v = G.qkv_rope(u_q[:T], u_k[:T], u_v[:T], st6[:T], cos, sin, B, S, Hl, Hkvl, D, 1e-5)
             self.kv.append((k, v))
-            o = pad(G.attention(q, k, v))
             # --- o_proj on the local heads' columns -> ONE reduction -> u on own rows -> LayerNorm + residual + RMSNorm fused
-            u_o = k_rows(sh.o, o, False)
+            if G is HipGlue:
+                hip_attn = self.attention == "hip" and D in (64, 128) and dt == torch.float16
+                o_pre = hip_attn and direct and T == Tp and sharded.hip_prescaled_ok(
+                    NShard(sh.o.weight, sh.o.input_factor, sh.o.weight_scale, None, 0, sh.o.out_features, sh.o.k1 - sh.o.k0, sh.o.out_features), Tp, dev)
+                o = pad(G.attention(q, k, v, "hip" if hip_attn else "sdpa", sh.o.input_factor if o_pre else None))
+            else:
+                o_pre = False
+                o = pad(G.attention(q, k, v))
+            u_o = k_rows(sh.o, o, o_pre)
             if pre((sh.gate, sh.up)):
                 h_own, (ag, au) = G.res_ln_rms(h_own, u_o, layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5,
                                                h_next=(sh.gate.input_factor, sh.up.input_factor))

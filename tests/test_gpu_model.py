@@ -163,11 +163,12 @@ def test_fused_tensor_parallel_prefill_world1_and_stats_kernels(golden_dir):
     model = build_synthetic_model(cfg, seed=6, device=dev)
     ids = torch.randint(0, 512, (3, 37), generator=torch.Generator().manual_seed(2)).to(dev)
     ref = model(ids)
-    tp = TensorParallelPrefill(model, 0, 1, attention="sdpa")
-    assert tp.fused
-    got = tp(ids)
     scale = float(ref.abs().max())
-    assert float((got - ref).abs().max()) <= 6e-3 * scale
+    for impl in ("sdpa", "hip"):
+        tp = TensorParallelPrefill(model, 0, 1, attention=impl)
+        assert tp.fused
+        got = tp(ids)
+        assert float((got - ref).abs().max()) <= 6e-3 * scale, impl
     assert tp.exchanges == 2 * cfg.num_hidden_layers and tp.kv[0][0].shape == (3, 4, 37, cfg.head_dim)
     assert not TensorParallelPrefill(model, 0, 1).fused              # attention="eager": torch glue, reference op order
     # the reference's own logits (tiny golden model b: every projection on the MFMA path)
@@ -177,7 +178,7 @@ def test_fused_tensor_parallel_prefill_world1_and_stats_kernels(golden_dir):
     gm = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
     gm.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")})
     gm = gm.to(dev).eval()
-    lg = TensorParallelPrefill(gm, 0, 1, attention="sdpa")(torch.from_numpy(z["input_ids"]).to(dev)).cpu().numpy()
+    lg = TensorParallelPrefill(gm, 0, 1, attention="hip")(torch.from_numpy(z["input_ids"]).to(dev)).cpu().numpy()
     ref16, ref32 = z["prefill_logits_f16"], z["prefill_logits_f32"]
     assert np.abs(lg - ref16).max() <= max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
     # *_stats kernels == the self-computing kernels when given the statistics those compute (fp32 two-pass here: the
