@@ -986,6 +986,8 @@ struct ObAttnArgs {
     float ln_eps;
     long long slot_stride;               // elements between the caches of consecutive slots (blockIdx.y); rows of
                                          // u_q / u_k / u_v / out are consecutive per slot
+    const _Float16 *h_next;              // optional [H * D]: out <- fp16(out * h_next), o_proj's input scaling (bitnet.py:113)
+                                         // for a consumer that takes pre-scaled rows (batched step, ob_skinny2.h)
 };
 
 // Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and
@@ -1261,7 +1263,9 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) acc += po[w * 128 + tid];
-        A.out[head * D + tid] = (_Float16)acc;
+        _Float16 oh = (_Float16)acc;
+        if (A.h_next) oh = oh * A.h_next[head * D + tid];
+        A.out[head * D + tid] = oh;
     }
 }
 

@@ -14,6 +14,7 @@
 #include "ob_gemm.h"
 #include "ob_gemm2.h"
 #include "ob_skinny.h"
+#include "ob_skinny2.h"
 #include "ob_batch.h"
 #include "ob_train.h"
 #include "ob_flash.h"
@@ -272,6 +273,9 @@ static void ob_launch_ln_f16(const float *z, const _Float16 *uin, const _Float16
 }
 
 struct ObGemvArgs;
+struct ObSk2Args;
+static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool dry);
+static bool ob_skinny2_shape_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K);
 static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s);
 static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const void *x, const void *h, const void *g,
                                 void *u, int64_t K, int64_t N, hipStream_t s);
@@ -336,6 +340,16 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
         } else if (T == 1 && K % 128 == 0 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && K <= 16384) {
             // one token: the persistent decode GEMV (plain prologue) instead of the 16-token tile kernel
             rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
+            if (rc) return rc;
+        } else if (prescaled && !ob_gemm3_ok(T, K, N)) {
+            // 2 <= T <= 32 on producer-scaled rows: the second-form skinny GEMM
+            ObSk2Args a = {};
+            a.lda = K; a.T = (int)T; a.K = (int)K;
+            a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, (int)N};
+            a.p[1] = a.p[0]; a.p[2] = a.p[0];
+            if (!ob_skinny2_shape_ok(packed, ldw_bytes, T, K) || !ob_launch_skinny2(a, 1, s, false))
+                return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
+            rc = ob_launch_status("linear_forward(skinny2)");
             if (rc) return rc;
         } else if (prescaled || (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
                                  ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32))) {
@@ -705,7 +719,15 @@ extern "C" int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, co
 // pre-scaled rows); the other kernels multiply by h on the way in and cannot skip it
 extern "C" int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype)
 {
-    return dtype == ONEBIT_F16 && T > 0 && K > 0 && N > 0 && K % 32 == 0 && ob_gemm3_ok(T, K, N) ? 1 : 0;
+    if (dtype != ONEBIT_F16 || T <= 0 || K <= 0 || N <= 0 || K % 32 != 0) return 0;
+    if (ob_gemm3_ok(T, K, N)) return 1;
+    // 2 <= T <= 32: the second-form skinny GEMM (ob_skinny2.h) consumes pre-scaled rows too, where an instance exists
+    if (T >= 2 && T <= 32 && K % 128 == 0 && K >= 512 && K <= 16384) {
+        ObSk2Args a = {};
+        a.T = (int)T; a.K = (int)K; a.p[0].N = a.p[1].N = a.p[2].N = (int)N;
+        return ob_launch_skinny2(a, 1, nullptr, true) ? 1 : 0;
+    }
+    return 0;
 }
 
 extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
@@ -781,6 +803,49 @@ extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
     return (size_t)m->n_heads * ((size_t)m->max_len * 4 + (size_t)S * 2 * 4 + (size_t)S * 128 * 4 + 4) + 64;
 }
 
+// ---- skinny GEMM, second form (ob_skinny2.h): pre-scaled rows, 2 <= T <= 32.  Instantiated where it measured faster than
+// the first form: ONE projection with ONE 512-weight chunk per wave (K <= 4096), up to 3 tile slots per workgroup; anything
+// else returns false and the caller takes the first form.
+template <int TT, int MS, int NPROJ, int KV>
+static void ob_launch_sk2_t(const ObSk2Args &a, int G, hipStream_t s)
+{
+    // staging images (8 waves x 16 TT rows x 512 B) reused as the reduction buffer (8 waves x MT x TT KB)
+    const size_t lds = std::max((size_t)OB_DEC_WAVES * MS * NPROJ * TT * 64 * 16, (size_t)OB_DEC_WAVES * 16 * TT * 512);
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_skinny2_kernel<TT, MS, NPROJ, KV>, attr_set, (int)lds);
+    hipLaunchKernelGGL((ob_skinny2_kernel<TT, MS, NPROJ, KV>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+}
+static bool ob_skinny2_shape_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K)
+{
+    return T >= 2 && T <= 32 && K % 128 == 0 && K >= 512 && K <= 16384 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16);
+}
+static bool ob_skinny2_ok(const onebit_proj_t &p, int64_t T, int64_t K)
+{
+    static const int env = getenv("OB_SKINNY2") ? atoi(getenv("OB_SKINNY2")) : 1;
+    return env && ob_skinny2_shape_ok(p.weight, p.ldw_bytes, T, K);
+}
+static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool dry)
+{
+    int max_tiles = 0;
+    for (int p = 0; p < nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
+    int G = ob_cu_count();
+    if (max_tiles < G) G = max_tiles;
+    const int MS = (max_tiles + G - 1) / G;
+    const int KV = (((a.K + 511) >> 9) + OB_DEC_WAVES - 1) / OB_DEC_WAVES;
+    const int TT = a.T <= 16 ? 1 : 2;
+    bool hit = false;
+#define OB_SK2(NP_, MS_, KV_)                                                             \
+    if (!hit && nproj == NP_ && MS == MS_ && KV == KV_) {                                 \
+        hit = true;                                                                       \
+        if (dry) { }                                                                      \
+        else if (TT == 1) ob_launch_sk2_t<1, MS_, NP_, KV_>(a, G, s);                     \
+        else ob_launch_sk2_t<2, MS_, NP_, KV_>(a, G, s);                                  \
+    }
+    OB_SK2(1, 1, 1) OB_SK2(1, 2, 1) OB_SK2(1, 3, 1)          // one projection, one chunk per wave (K <= 4096), N up to 48 x CUs rows
+#undef OB_SK2
+    return hit;
+}
+
 extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
 {
     if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
@@ -838,13 +903,11 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             }
             return ob_launch_status("decode_step_batched(gemm)");
         }
-        // OB_SKINNY_WIDE=1: 128-row workgroups for the wide launches (q|k|v, gate|up) -- half the activation
-        // traffic out of L2, half the workgroups.  Measured SLOWER (32-slot 7B step 2.85 vs 2.75 ms): off.
-        int64_t nsum = 0;
-        for (int i = 0; i < np; ++i) nsum += ps.p[i]->N;
-        static const int wide_env = getenv("OB_SKINNY_WIDE") ? atoi(getenv("OB_SKINNY_WIDE")) : 0;
-        const bool wide = wide_env && nsum >= 96 * 128 && B <= 32;
-        const int rows = wide ? 128 : 64;
+        // (64 rows per workgroup.  Other tile counts were measured, 32 slots: 128 rows for the wide launches 2.85 vs 2.75 ms
+        //  (round 2); 48 rows for q|k|v / 96 for gate|up -- grids of 258 / 230 workgroups for 256 CUs -- 15.5 / 14.1 us against
+        //  14.7 / 14.7 at 7B and slower at 13B (round 3): what bounds these launches is the [T, K] activation block every
+        //  workgroup pulls out of L2, not the grid fit)
+        const int rows = 64;
         ObSkinnyArgs ka = {};
         int tiles = 0;
         for (int i = 0; i < 3; ++i) {
@@ -857,9 +920,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         }
         stats_written = ss.s[0] != nullptr;
         ka.ldx = K; ka.T = B;
-        if (wide && B <= 16) ob_launch_skinny<false, 1, 8>(ka, tiles, s);
-        else if (wide) ob_launch_skinny<false, 2, 8>(ka, tiles, s);
-        else if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
+        if (B <= 16) ob_launch_skinny<false, 1>(ka, tiles, s);
         else if (B <= 32) ob_launch_skinny<false, 2>(ka, tiles, s);
         else ob_launch_skinny<false, 4>(ka, tiles, s);
         return ob_launch_status("decode_step_batched(gemm)");
@@ -889,6 +950,20 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         splitk_o = m->layers[l].o.weight && m->layers[l].o.ldw_bytes % 16 == 0 &&
                    ob_skinny_ok((const uint32_t *)m->layers[l].o.weight + (H / 2) / 32, m->layers[l].o.ldw_bytes, B, H / 2) &&
                    ob_skinny_ok(m->layers[l].o.weight, m->layers[l].o.ldw_bytes, B, H / 2);
+    // o_proj through the second-form skinny GEMM (ob_skinny2.h) where it applies (2 <= B <= 32, hidden <= 4096: one
+    // 512-weight chunk per wave): the attention kernel then writes its rows times o_proj's input_factor.  Measured at
+    // 7B, 32 slots: 7.9 us against 10.6 us for the split-K first form; the same kernel on the launches with several
+    // projections or several chunks per wave re-reads one [B, K] activation block per projection and chunk out of L2 in
+    // every workgroup and measured slower (q|k|v 22.4, gate|up 18.1, down 16.7 us against 14.8 / 14.8 / 10.6): not used there
+    bool o_sk2 = B <= 32 && NQ == H;
+    for (int l = 0; o_sk2 && l < m->n_layers; ++l) {
+        const onebit_proj_t &po = m->layers[l].o;
+        ObSk2Args ka = {};
+        ka.T = B; ka.K = NQ; ka.p[0].N = ka.p[1].N = ka.p[2].N = H;
+        o_sk2 = po.weight && po.input_factor && po.weight_scale && po.K == NQ && po.N == H && ob_skinny2_ok(po, B, NQ) &&
+                ob_launch_skinny2(ka, 1, s, true);
+    }
+    if (o_sk2) splitk_o = false;
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -925,13 +1000,23 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
+        if (o_sk2) at.h_next = (const _Float16 *)L.o.input_factor;
         if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
+        if (o_sk2) {
+            ObSk2Args ka = {};
+            ka.lda = NQ; ka.T = B; ka.K = NQ;
+            ka.p[0] = {(const uint32_t *)L.o.weight, (long long)(L.o.ldw_bytes / 4), (const _Float16 *)L.o.weight_scale,
+                       (const _Float16 *)st->attn_out, (_Float16 *)st->u_o, nullptr, H};
+            ka.p[1] = ka.p[0]; ka.p[2] = ka.p[0];
+            (void)ob_launch_skinny2(ka, 1, s, false);
+            if ((rc = ob_launch_status("decode_step_batched(o)"))) return rc;
+        }
+        else if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
         else if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
         // 5. residual + LayerNorm(u_o) + post-attention RMSNorm
         ObBNormArgs nb = na;
@@ -942,7 +1027,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
         if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
-        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr};
+        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr, nullptr};
         hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges

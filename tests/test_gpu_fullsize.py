@@ -316,3 +316,24 @@ def test_prescaled_route_is_bit_identical_at_full_size():
     assert not small.prescaled_ok(8)
     with pytest.raises(Exception):
         small.pre_layernorm_prescaled(torch.zeros(8, 512, dtype=torch.float16, device=dev))
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (1024, 528), (512, 48)])
+@pytest.mark.parametrize("T", [2, 7, 16, 17, 32])
+def test_second_form_skinny_gemm_on_prescaled_rows_vs_oracle(coracle, K, N, T):
+    """ob_skinny2.h (2 <= T <= 32 tokens on producer-scaled rows fp16(x * h), one 512-weight chunk per wave: the batched
+    step's o_proj and the ONEBIT_FLAG_PRESCALED route of short prompts) against the oracle's complete layer: u within
+    2 fp16 ulps, and equal to the first form up to the fp32 summation order."""
+    dev = torch.device("cuda:0")
+    m, packed, h, g = _mk(K, N, 1000 + K + N, dev)
+    assert m.prescaled_ok(T)
+    x = np.random.default_rng(T).standard_normal((T, K)).astype(np.float16)
+    xt = torch.from_numpy(x).to(dev)
+    a = xt * m.input_factor.data                               # the producer's rounding (bitnet.py:113)
+    u2 = m.pre_layernorm_prescaled(a).cpu().numpy()
+    u1 = m.pre_layernorm(xt).cpu().numpy()
+    _, u_ref = coracle.forward_f16(packed, x, h, g, None, return_pre_ln=True)
+    for t in range(T):
+        _check_u(u2[t], u_ref[t], "K=%d N=%d T=%d row %d" % (K, N, T, t))
+    assert (u1 != u2).mean() <= 0.02
+    assert not m.prescaled_ok(33) or K * N >= 4096 * 4096        # beyond 32 tokens only the LDS-DMA GEMM takes pre-scaled rows
