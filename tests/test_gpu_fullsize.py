@@ -273,7 +273,7 @@ def test_prescaled_route_is_bit_identical_at_full_size():
     """ONEBIT_FLAG_PRESCALED (BASELINE config 3 shape, T = 16384): the producer kernels write fp16(x * h) themselves
     (onebit_rows_res_ln_rms with h_next, onebit_rows_swiglu with h_next) and the projection skips its scaling pass --
     the same kernel on the same rows, so the pre-LayerNorm output must equal the ordinary call's bit for bit; the
-    flag is refused on a shape that does not take the LDS-DMA GEMM."""
+    flag is refused on a call no pre-scaled kernel takes."""
     import ctypes
     from onebit_amd import _lib
     from onebit_amd.bitnet import _stream_ptr
@@ -313,9 +313,10 @@ def test_prescaled_route_is_bit_identical_at_full_size():
     assert torch.equal(act_s, act * hd)
     # a shape on another kernel route refuses the flag
     small, *_ = _mk(512, 64, 5, dev)
-    assert not small.prescaled_ok(8)
+    assert small.prescaled_ok(8)                                    # 2 <= T <= 32: the second-form skinny GEMM takes scaled rows
+    assert not small.prescaled_ok(40)                               # 40 tokens: neither that nor the LDS-DMA GEMM
     with pytest.raises(Exception):
-        small.pre_layernorm_prescaled(torch.zeros(8, 512, dtype=torch.float16, device=dev))
+        small.pre_layernorm_prescaled(torch.zeros(40, 512, dtype=torch.float16, device=dev))
 
 
 @pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (1024, 528), (512, 48)])
