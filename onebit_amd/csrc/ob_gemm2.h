@@ -250,13 +250,18 @@ __global__ __launch_bounds__(256) void ob_scale_rows_kernel(const _Float16 *__re
 
 #define OB_G3_BUFS 4
 #define OB_G3_LDS (OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2 + 2 * 8192)      // 4 activation tiles + 2 weight quads
-template <bool PARTIAL>
-__global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
+#define OB_G3_LDS_W(WT_) (OB_G3_BUFS * 128 * (WT_) * OB_G2_PITCH * 2 + 2 * 8192)
+// WT = token-side waves: 2 = the 256 x 256 / 8-wave workgroup described above (one per CU: 147 KB of LDS); 1 = 256 rows x
+// 128 tokens / 4 waves (80 KB: TWO workgroups per CU, each with its own barrier -- while one waits the other multiplies;
+// the same wave tile, the same activation traffic per flop, twice the (tiny) weight traffic).
+template <bool PARTIAL, int WT = 2>
+__global__ __launch_bounds__(256 * WT, 2) void ob_gemm3_f16_kernel(
     const uint32_t *__restrict__ W, int64_t ldw_words, const _Float16 *__restrict__ a, int64_t lda,
     const _Float16 *__restrict__ g, _Float16 *__restrict__ u, float *__restrict__ zp, int T, int K, int N, int nbn)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16 (*As)[OB_G2_T][OB_G2_PITCH] = reinterpret_cast<_Float16 (*)[OB_G2_T][OB_G2_PITCH]>(smem);
+    constexpr int TTILE = 128 * WT;              // tokens per workgroup tile
+    _Float16 (*As)[TTILE][OB_G2_PITCH] = reinterpret_cast<_Float16 (*)[TTILE][OB_G2_PITCH]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 3, wt = wave >> 2;
     const int r = lane & 15, gq = lane >> 4;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
     const int xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
     const int bid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
     const int tt = bid / nbn, tn = bid - tt * nbn;
-    const int n0 = tn * OB_G2_N, t0 = tt * OB_G2_T;
+    const int n0 = tn * OB_G2_N, t0 = tt * TTILE;
     const int nk = K / OB_G2_K;                 // K % 256 == 0 here (host-checked): whole quads of steps
 
     // DMA source of this lane for each of the wave's 4 instructions per tile, as a 32-bit BYTE offset from
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
         const uint32_t kofs = (uint32_t)((tile >> 1) * 128 + (tile & 1) * 32) * 2u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            dma16(abase, src[i] + kofs, lds0 + (buf * OB_G2_T + (wave_u * 4 + i) * 8) * (OB_G2_PITCH * 2));
+            dma16(abase, src[i] + kofs, lds0 + (buf * TTILE + (wave_u * 4 + i) * 8) * (OB_G2_PITCH * 2));
     };
     // Weights go through LDS as well: while LDS-DMA transfers are pending hipcc turns EVERY wait for an
     // ordinary global load into vmcnt(0) (and an asm load's destination registers are fair game for its
@@ -312,9 +317,13 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
     // the two halves of a lane group pair broadcast).
     const char *wbase = reinterpret_cast<const char *>(W);
     const uint32_t wsrc = (uint32_t)((int64_t)min(n0 + 32 * wave + (lane & 31), N - 1) * ldw_words * 4 + 16 * (lane >> 5));
-    char *wlds = smem + OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2;
+    // (4-wave form: a wave fetches two 32-row blocks per quad, its own and the one 4 waves up)
+    const uint32_t wsrc2 = (uint32_t)((int64_t)min(n0 + 32 * (wave + 4) + (lane & 31), N - 1) * ldw_words * 4 + 16 * (lane >> 5));
+    char *wlds = smem + OB_G3_BUFS * TTILE * OB_G2_PITCH * 2;
     auto wdma = [&](int quad) {
-        dma16(wbase, wsrc + 32u * (uint32_t)quad, lds0 + OB_G3_BUFS * OB_G2_T * OB_G2_PITCH * 2 + ((uint32_t)quad & 1) * 8192 + wave_u * 1024);
+        dma16(wbase, wsrc + 32u * (uint32_t)quad, lds0 + OB_G3_BUFS * TTILE * OB_G2_PITCH * 2 + ((uint32_t)quad & 1) * 8192 + wave_u * 1024);
+        if (WT == 1)
+            dma16(wbase, wsrc2 + 32u * (uint32_t)quad, lds0 + OB_G3_BUFS * TTILE * OB_G2_PITCH * 2 + ((uint32_t)quad & 1) * 8192 + (wave_u + 4) * 1024);
     };
     // row wn * 64 + rn * 16 + r: block (row >> 5) = 2 wn + (rn >> 1), row-in-block (rn & 1) * 16 + r
     const char *wrd = wlds + wn * 2048 + r * 16 + 8 * (gq >> 1);
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(OB_G2_THREADS, 2) void ob_gemm3_f16_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         if (OB_G3_ABL & 8) {                                                                                             \
         } else if (STEADY) {                                                                                             \
-            if ((Q) == 1 || (Q) == 2) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+            if (((Q) == 1 || (Q) == 2) && WT == 1) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+            else if ((Q) == 1 || (Q) == 2) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");      \
             else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                \
         } else {                                                                                                         \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \

@@ -294,6 +294,29 @@ static bool ob_gemm3_ok(int64_t T, int64_t K, int64_t N)
     return tiles >= 4 * cu || (tiles >= cu && 3 * tiles >= 2 * rounds * cu) || env == 2;
 }
 
+// The LDS-DMA GEMM in its 8-wave (256 x 256 tile, one workgroup per CU) or 4-wave (256 rows x 128 tokens, two workgroups per
+// CU) form; OB_GEMM3_WT=1 / 2 selects (A/B), default below.
+template <bool PARTIAL>
+static void ob_launch_gemm3(const uint32_t *W, int64_t ldw_words, const _Float16 *a, int64_t lda, const _Float16 *g, _Float16 *u,
+                            float *zp, int64_t T, int64_t K, int64_t N, hipStream_t s)
+{
+    static const int wt_env = getenv("OB_GEMM3_WT") ? atoi(getenv("OB_GEMM3_WT")) : 1;    // 4-wave form: +3-4 % (1286 -> 1335 TFLOP/s on 4096 -> 11008), bit-identical
+    const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N);
+    if (wt_env == 1) {
+        static bool attr_set[OB_MAX_DEVICES] = {};
+        ob_set_max_lds_once(ob_gemm3_f16_kernel<PARTIAL, 1>, attr_set, OB_G3_LDS_W(1));
+        const int nbt = (int)((T + 127) / 128);
+        hipLaunchKernelGGL((ob_gemm3_f16_kernel<PARTIAL, 1>), dim3((unsigned)(nbn * nbt)), dim3(256), OB_G3_LDS_W(1), s,
+                           W, ldw_words, a, lda, g, u, zp, (int)T, (int)K, (int)N, nbn);
+    } else {
+        static bool attr_set[OB_MAX_DEVICES] = {};
+        ob_set_max_lds_once(ob_gemm3_f16_kernel<PARTIAL, 2>, attr_set, OB_G3_LDS);
+        const int nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
+        hipLaunchKernelGGL((ob_gemm3_f16_kernel<PARTIAL, 2>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
+                           W, ldw_words, a, lda, g, u, zp, (int)T, (int)K, (int)N, nbn);
+    }
+}
+
 // bytes a call cannot do without (F32: fp32 z is staged in y itself; F16 on the MFMA path: u is staged in
 // y; F16 shapes the MFMA path cannot take (K % 32 != 0) stage fp32 z in the workspace)
 static size_t ob_required_workspace(int64_t T, int64_t K, int64_t N, int dtype)
@@ -362,12 +385,7 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
                                    (const _Float16 *)h, (_Float16 *)workspace, T, (int)K);
                 a = (const _Float16 *)workspace;
             }
-            static bool attr_set[OB_MAX_DEVICES] = {};
-            ob_set_max_lds_once(ob_gemm3_f16_kernel<false>, attr_set, OB_G3_LDS);
-            const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
-            hipLaunchKernelGGL((ob_gemm3_f16_kernel<false>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
-                               (const uint32_t *)packed, ldw_bytes / 4, a, K, (const _Float16 *)g, ubuf, nullptr,
-                               (int)T, (int)K, (int)N, nbn);
+            ob_launch_gemm3<false>((const uint32_t *)packed, ldw_bytes / 4, a, K, (const _Float16 *)g, ubuf, nullptr, T, K, N, s);
             rc = ob_launch_status("linear_forward(gemm3)");
             if (rc) return rc;
         } else {
@@ -428,12 +446,7 @@ extern "C" int onebit_matmul_partial_ws(const void *packed, int64_t ldw_bytes, c
         const int64_t nvec = T * K / 8;
         hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, ldx,
                            (const _Float16 *)h, a, T, (int)K);
-        static bool attr_set[OB_MAX_DEVICES] = {};
-        ob_set_max_lds_once(ob_gemm3_f16_kernel<true>, attr_set, OB_G3_LDS);
-        const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + OB_G2_T - 1) / OB_G2_T);
-        hipLaunchKernelGGL((ob_gemm3_f16_kernel<true>), dim3((unsigned)(nbn * nbt)), dim3(OB_G2_THREADS), OB_G3_LDS, s,
-                           (const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)a, K, nullptr, nullptr, zp,
-                           (int)T, (int)K, (int)N, nbn);
+        ob_launch_gemm3<true>((const uint32_t *)packed, ldw_bytes / 4, (const _Float16 *)a, K, nullptr, nullptr, zp, T, K, N, s);
     } else if (ob_mfma_ok(packed, ldw_bytes, ldx, K, dtype))
         ob_launch_mm16<true>(packed, ldw_bytes, x, ldx, h, nullptr, nullptr, zp, T, K, N, s);
     else if (dtype == ONEBIT_F16)
