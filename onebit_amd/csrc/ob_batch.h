@@ -28,17 +28,19 @@ struct ObBNormArgs {
     int n_scaled;
 };
 
-template <bool EMBED>
+// NV = 8-half vectors per thread actually populated: ceil(H / 4096).  (Sized OB_DEC_MAXV = 4 for every width, a 4096-wide
+// row executed four times the loads, reductions and stores it needed, three quarters of them masked.)
+template <bool EMBED, int NV>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNormArgs A)
 {
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, H = A.H;
     const int64_t row = (int64_t)blockIdx.x * H;
     const _Float16 *src = EMBED ? A.embed + (int64_t)A.tokens[blockIdx.x] * H : A.hres_in + row;
-    ob_half8 hv[OB_DEC_MAXV], uv[OB_DEC_MAXV];
-    bool valid[OB_DEC_MAXV];
+    ob_half8 hv[NV], uv[NV];
+    bool valid[NV];
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         valid[v] = base < H;
         hv[v] = *reinterpret_cast<const ob_half8 *>(src + (valid[v] ? base : 0));
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
                                   : (float)(_Float16)(ob_round_h(A.z0[row] + A.z1[row]) * (float)A.g_prev[0]);
         ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v)
+        for (int v = 0; v < NV; ++v)
             if (valid[v]) ob_stats8(uv[v], c0, s2, q2);
         float s[2] = {s2[0] + s2[1], q2[0] + q2[1]};
         ob_block_sum_n<2, OB_DEC_WAVES>(s, red);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
         ob_ln_stats(s[0], s[1], c0, H, A.ln_eps, mean, rstd);
         const float nmr = -mean * rstd;
 #pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             ob_half8 ln;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ln[i] = ob_ln_apply_h(uv[v][i], rstd, nmr);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     }
     float ss[1] = {0.f};
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         if (valid[v]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     ob_block_sum_n<1, OB_DEC_WAVES>(ss, red + 64);
     const float rs = __builtin_amdgcn_rsqf(ss[0] * __builtin_amdgcn_rcpf((float)H) + A.rms_eps);
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         if (valid[v]) {
             const ob_half8 w = *reinterpret_cast<const ob_half8 *>(A.rms_w + base);
@@ -120,15 +122,16 @@ struct ObBSwigluArgs {
                                      // column slice (tensor-parallel N-shard), their statistics were combined across ranks
 };
 
+template <int NV>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSwigluArgs A)
 {
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, I = A.I;
     const int64_t row = (int64_t)blockIdx.x * I;
-    ob_half8 g8[OB_DEC_MAXV], u8[OB_DEC_MAXV];
-    bool valid[OB_DEC_MAXV];
+    ob_half8 g8[NV], u8[NV];
+    bool valid[NV];
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         valid[v] = base < I;
         g8[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + row + (valid[v] ? base : 0));
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
         const float c0 = (float)A.u_gate[row], c1 = (float)A.u_up[row];
         ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v)
+        for (int v = 0; v < NV; ++v)
             if (valid[v]) { ob_stats8(g8[v], c0, sg2, qg2); ob_stats8(u8[v], c1, su2, qu2); }
         float s[4] = {sg2[0] + sg2[1], qg2[0] + qg2[1], su2[0] + su2[1], qu2[0] + qu2[1]};
         ob_block_sum_n<4, OB_DEC_WAVES>(s, red);
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
     }
     const float ng = -mg * rg, nu = -mu * ru;
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         if (valid[v]) {
             ob_half8 sg, up;
@@ -190,6 +193,7 @@ struct ObQkvRopeArgs {
                                          // given here hold the rank's heads only)
 };
 
+template <int NV>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkvRopeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float red[128];
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
     const _Float16 *uq = A.u_q + (int64_t)t * NQ, *uk = A.u_k + (int64_t)t * NK, *uv = A.u_v + (int64_t)t * NK;
     // thread owns 8 consecutive elements of each vector per pass (D % 8 == 0: never straddles a head), and
     // fetches their rotate_half partners (same head, d +- D/2) alongside
-    ob_half8 q8[OB_DEC_MAXV], qp8[OB_DEC_MAXV], k8[OB_DEC_MAXV], kp8[OB_DEC_MAXV], v8[OB_DEC_MAXV];
-    bool vq[OB_DEC_MAXV], vk[OB_DEC_MAXV];
+    ob_half8 q8[NV], qp8[NV], k8[NV], kp8[NV], v8[NV];
+    bool vq[NV], vk[NV];
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         vq[v] = base < NQ; vk[v] = base < NK;
         const int bq = vq[v] ? base : 0, bk = vk[v] ? base : 0;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
     // aligned groups of D/8 lanes) -- a lane exchange instead of a second pass over the rows.  Lanes beyond the
     // vector hold clamped copies of lane 0's chunk and exchange among themselves.
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const ob_u32x4 qa = __builtin_bit_cast(ob_u32x4, q8[v]), ka = __builtin_bit_cast(ob_u32x4, k8[v]);
         ob_u32x4 qb, kb;
 #pragma unroll
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
         const float cq = (float)uq[0], ck = (float)uk[0], cv = (float)uv[0];
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int v = 0; v < OB_DEC_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             if (vq[v]) ob_stats8(q8[v], cq, a2[0], a2[1]);
             if (vk[v]) { ob_stats8(k8[v], ck, a2[2], a2[3]); ob_stats8(v8[v], cv, a2[4], a2[5]); }
         }
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
     }
     const _Float16 *cosr = A.cos + (int64_t)pos * D, *sinr = A.sin + (int64_t)pos * D;
 #pragma unroll
-    for (int v = 0; v < OB_DEC_MAXV; ++v) {
+    for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         if (vq[v]) {
             const int hd = base / D, d0 = base - hd * D;

@@ -19,6 +19,25 @@
 #include "ob_train.h"
 #include "ob_flash.h"
 
+// row kernels are instantiated per number of populated 8-half vectors per thread (ceil(width / 4096), 1..4)
+#define OB_NV_DISPATCH(WIDTH, CALL1, CALL2, CALL3, CALL4) \
+    do { const int nv_ = (int)(((WIDTH) + 4095) / 4096); if (nv_ <= 1) { CALL1; } else if (nv_ == 2) { CALL2; } else if (nv_ == 3) { CALL3; } else { CALL4; } } while (0)
+#define OB_LAUNCH_NORM(EMBED_, WIDTH, GRID, STREAM, ARGS) \
+    OB_NV_DISPATCH(WIDTH, hipLaunchKernelGGL((ob_b_norm_kernel<EMBED_, 1>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_norm_kernel<EMBED_, 2>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_norm_kernel<EMBED_, 3>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_norm_kernel<EMBED_, 4>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
+#define OB_LAUNCH_SWIGLU(WIDTH, GRID, STREAM, ARGS) \
+    OB_NV_DISPATCH(WIDTH, hipLaunchKernelGGL((ob_b_swiglu_kernel<1>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_swiglu_kernel<2>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_swiglu_kernel<3>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_b_swiglu_kernel<4>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
+#define OB_LAUNCH_QKVROPE(WIDTH, GRID, STREAM, ARGS) \
+    OB_NV_DISPATCH(WIDTH, hipLaunchKernelGGL((ob_qkv_rope_kernel<1>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<2>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<3>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<4>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
+
 static thread_local char g_err[256] = "";
 
 static int ob_fail(int code, const char *fmt, ...)
@@ -281,17 +300,18 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
                                 void *u, int64_t K, int64_t N, hipStream_t s);
 
 // The LDS-DMA prefill GEMM (ob_gemm3_f16_kernel) consumes pre-scaled activations from the caller's
-// workspace; eligible from ~4 rounds of 256 x 256 tiles over the CUs.  OB_GEMM3=0 disables it (A/B).
+// workspace (or the producer's rows).  OB_GEMM3=0 disables it (A/B), =2 forces it on any eligible shape.
+// Eligibility: since the 4-wave form (256 rows x 128 tokens, two workgroups per CU) it wins from a grid of about two
+// thirds of the CU count -- measured with the scaling pass included, default dispatch vs forced (tools/gemm_route_probe.py):
+// 172 workgroups ([512, 4096] -> 11008) 664 vs 569 TFLOP/s, 256 ([2048, 4096] -> 4096) 863 vs 787, 344 ([1024, 4096] ->
+// 11008) 856 vs 693, 516 ([1536, 4096] -> 11008) 863 vs 683; 128 workgroups ([1024, 4096] -> 4096) 494 vs 609: not taken.
 static bool ob_gemm3_ok(int64_t T, int64_t K, int64_t N)
 {
     static const int env = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
     // whole quads of K steps; 32-bit byte offsets from the base pointers inside the kernel
     if (!env || T < 192 || K % (4 * OB_G2_K) != 0 || N % 4 != 0 || T * K * 2 >= ((int64_t)1 << 32) || N * (K / 8) >= ((int64_t)1 << 32)) return false;
-    const int64_t tiles = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + OB_G2_T - 1) / OB_G2_T);
-    // from ~4 rounds of tiles always; below that when the last round is at least two thirds full
-    // ([2048, 4096] -> 11008: 344 tiles on 256 CUs, 974 vs 903 TFLOP/s for the 128 x 128 kernel; 43 tiles: 258 vs 446)
-    const int64_t cu = ob_cu_count(), rounds = (tiles + cu - 1) / cu;
-    return tiles >= 4 * cu || (tiles >= cu && 3 * tiles >= 2 * rounds * cu) || env == 2;
+    const int64_t tiles = ((N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
+    return 3 * tiles >= 2 * (int64_t)ob_cu_count() || env == 2;
 }
 
 // The LDS-DMA GEMM in its 8-wave (256 x 256 tile, one workgroup per CU) or 4-wave (256 rows x 128 tokens, two workgroups per
@@ -702,7 +722,7 @@ extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, c
         if (!h_next[i] || !x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null scaled output %d", i);
         a.h_next[i] = (const _Float16 *)h_next[i]; a.x_scaled[i] = (_Float16 *)x_scaled[i];
     }
-    hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    OB_LAUNCH_NORM(false, H, dim3((unsigned)T), (hipStream_t)stream, a);
     return ob_launch_status("rows_res_ln_rms");
 }
 
@@ -724,7 +744,7 @@ extern "C" int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, co
     if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_swiglu: dimension too large");
     if (row_stats && !ob_aligned(row_stats, 16)) return ob_fail(ONEBIT_E_ALIGN, "rows_swiglu: row_stats must be 16-byte aligned");
     ObBSwigluArgs a = {(const _Float16 *)u_gate, (const _Float16 *)u_up, (_Float16 *)act, (int)I, ln_eps, (const _Float16 *)h_next, row_stats};
-    hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    OB_LAUNCH_SWIGLU(I, dim3((unsigned)T), (hipStream_t)stream, a);
     return ob_launch_status("rows_swiglu");
 }
 
@@ -776,7 +796,7 @@ extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, cons
     ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
                        (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, (int)S, n_heads, n_kv_heads, head_dim, (int)past_len,
                        (int)max_len, (flags & ONEBIT_FLAG_Q_TOKEN_MAJOR) ? 1 : 0, ln_eps, row_stats};
-    hipLaunchKernelGGL(ob_qkv_rope_kernel, dim3((unsigned)(B * S)), dim3(OB_DEC_THREADS), 0, (hipStream_t)stream, a);
+    OB_LAUNCH_QKVROPE((int64_t)n_heads * head_dim, dim3((unsigned)(B * S)), (hipStream_t)stream, a);
     return ob_launch_status("rows_qkv_rope");
 }
 
@@ -988,8 +1008,8 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         else na.u_prev = (const _Float16 *)st->u_down;
         na.rms_w = (const _Float16 *)L.input_layernorm_w; na.hres_out = hB; na.x = (_Float16 *)st->x; na.H = H;
         na.rms_eps = m->rms_eps; na.ln_eps = m->ln_eps;
-        if (l == 0) hipLaunchKernelGGL(ob_b_norm_kernel<true>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
-        else hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, na);
+        if (l == 0) OB_LAUNCH_NORM(true, H, dim3(B), s, na);
+        else OB_LAUNCH_NORM(false, H, dim3(B), s, na);
         if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
         // 2. q, k, v: one launch when the skinny kernel takes all three
         //    (its epilogue also publishes the LayerNorm partials of the three rows per slot, so the (head, slot)
@@ -1036,12 +1056,12 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
         if (splitk_o) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; } nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
-        hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nb);
+        OB_LAUNCH_NORM(false, H, dim3(B), s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
         if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
         ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr, nullptr};
-        hipLaunchKernelGGL(ob_b_swiglu_kernel, dim3(B), dim3(OB_DEC_THREADS), 0, s, sa);
+        OB_LAUNCH_SWIGLU(I, dim3(B), s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges
         //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
@@ -1055,7 +1075,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     if (splitk_down) { nf.u_prev = nullptr; nf.z0 = zs0; nf.z1 = zs1; nf.g_prev = (const _Float16 *)m->layers[m->n_layers - 1].down.weight_scale; }
     else nf.u_prev = (const _Float16 *)st->u_down;
     nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
-    hipLaunchKernelGGL(ob_b_norm_kernel<false>, dim3(B), dim3(OB_DEC_THREADS), 0, s, nf);
+    OB_LAUNCH_NORM(false, H, dim3(B), s, nf);
     if ((rc = ob_launch_status("decode_step_batched(final norm)"))) return rc;
     if (!st->next_tokens) return 0;
     // batched lm_head + greedy sampling
