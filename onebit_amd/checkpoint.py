@@ -19,7 +19,7 @@ import torch
 from .llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
 
 _CFG_KEYS = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
-             "num_key_value_heads", "max_position_embeddings", "rms_norm_eps", "rope_theta", "attention_bias")
+             "num_key_value_heads", "max_position_embeddings", "rms_norm_eps", "rope_theta", "attention_bias", "rope_scaling")
 WEIGHTS_NAME = "pytorch_model.bin"
 
 
@@ -28,8 +28,6 @@ def config_from_json(path: str) -> OneBitLlamaConfig:
         raw = json.load(f)
     if raw.get("model_type", "bitllama") != "bitllama":
         raise ValueError(f"not a OneBit checkpoint: model_type={raw.get('model_type')!r}")
-    if raw.get("rope_scaling") is not None:
-        raise NotImplementedError("rope_scaling is not supported")
     if raw.get("pretraining_tp", 1) != 1:
         raise NotImplementedError("pretraining_tp > 1 (dead code in the reference's Inf classes, SURVEY.md fact 9)")
     if raw.get("hidden_act", "silu") != "silu":
@@ -40,7 +38,7 @@ def config_from_json(path: str) -> OneBitLlamaConfig:
 def config_to_json(cfg: OneBitLlamaConfig) -> dict:
     d = {k: getattr(cfg, k) for k in _CFG_KEYS}
     d.update(model_type="bitllama", architectures=["BitLlamaForCausalLMInf"], hidden_act="silu",
-             pretraining_tp=1, rope_scaling=None, tie_word_embeddings=False, torch_dtype="float16")
+             pretraining_tp=1, tie_word_embeddings=False, torch_dtype="float16")
     return d
 
 

@@ -42,12 +42,21 @@ class OneBitLlamaConfig:
     rms_norm_eps: float = 1e-6
     rope_theta: float = 10000.0
     attention_bias: bool = False
+    rope_scaling: Optional[dict] = None       # {"type": "linear" | "dynamic", "factor": float > 1}, configuration_bitllama.py:168-187
 
     def __post_init__(self):
         if self.num_key_value_heads is None:
             self.num_key_value_heads = self.num_attention_heads
         if self.hidden_size % self.num_attention_heads:
             raise ValueError("hidden_size must be divisible by num_heads")
+        if self.rope_scaling is not None:           # the reference's _rope_scaling_validation
+            rs = self.rope_scaling
+            if not isinstance(rs, dict) or len(rs) != 2:
+                raise ValueError(f"`rope_scaling` must be a dictionary with two fields, `type` and `factor`, got {rs}")
+            if rs.get("type") not in ("linear", "dynamic"):
+                raise ValueError(f"`rope_scaling`'s type field must be one of ['linear', 'dynamic'], got {rs.get('type')}")
+            if not isinstance(rs.get("factor"), float) or rs["factor"] <= 1.0:
+                raise ValueError(f"`rope_scaling`'s factor field must be a float > 1, got {rs.get('factor')}")
 
     @property
     def head_dim(self) -> int:
@@ -79,10 +88,19 @@ class LlamaRMSNorm(nn.Module):
         return self.weight * hidden_states.to(input_dtype)
 
 
-def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype):
-    """cos/sin caches of LlamaRotaryEmbedding (:87-113): fp32 tables cast to the model dtype."""
+def rope_tables(head_dim: int, max_pos: int, base: float, device, dtype, seq_len: Optional[int] = None,
+                scaling: Optional[dict] = None):
+    """cos/sin caches of LlamaRotaryEmbedding (:87-113) for `seq_len` (default max_pos) positions: fp32 tables cast to
+    the model dtype.  ``scaling``: the reference's two variants -- "linear" (positions divided by the factor, :125-141)
+    and "dynamic" NTK (the base grows once the cached length exceeds max_position_embeddings, :144-165)."""
+    n = max_pos if seq_len is None else seq_len
+    if scaling is not None and scaling["type"] == "dynamic" and n > max_pos:
+        f = float(scaling["factor"])
+        base = base * ((f * n / max_pos) - (f - 1)) ** (head_dim / (head_dim - 2))
     inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32, device=device) / head_dim))
-    t = torch.arange(max_pos, dtype=torch.float32, device=device)
+    t = torch.arange(n, dtype=torch.float32, device=device)
+    if scaling is not None and scaling["type"] == "linear":
+        t = t / float(scaling["factor"])
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -234,10 +252,16 @@ class OneBitLlamaForCausalLM(nn.Module):
         self.lm_head.weight.requires_grad_(False)
         self._rope = None
 
-    def _rope_tables(self, device, dtype):
-        if self._rope is None or self._rope[0].device != device or self._rope[0].dtype != dtype:
-            self._rope = rope_tables(self.config.head_dim, self.config.max_position_embeddings,
-                                     self.config.rope_theta, device, dtype)
+    def _rope_tables(self, device, dtype, seq_len: Optional[int] = None):
+        """The rotary caches, grown on demand as the reference's ``LlamaRotaryEmbedding.forward`` does (:106-108): built for
+        max_position_embeddings, rebuilt for ``seq_len`` positions the first time a pass needs more (with "dynamic"
+        scaling that rebuild also rescales the base for that length -- and, as in the reference, it stays rescaled)."""
+        cfg = self.config
+        have = 0 if self._rope is None else self._rope[0].shape[0]
+        need = max(cfg.max_position_embeddings, seq_len or 0, have)
+        if self._rope is None or self._rope[0].device != device or self._rope[0].dtype != dtype or need > have:
+            self._rope = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, device, dtype,
+                                     seq_len=need, scaling=cfg.rope_scaling)
         return self._rope
 
     def set_attention(self, impl: str) -> "OneBitLlamaForCausalLM":
@@ -271,7 +295,7 @@ class OneBitLlamaForCausalLM(nn.Module):
         B, S = input_ids.shape
         T, H, I = B * S, cfg.hidden_size, cfg.intermediate_size
         h = m.embed_tokens(input_ids).reshape(T, H)
-        cos, sin = self._rope_tables(h.device, h.dtype)
+        cos, sin = self._rope_tables(h.device, h.dtype, past + S)
         sp = _stream_ptr(h.device)
 
         def res_ln_rms(hres, u, w, consumers=()):
@@ -366,7 +390,7 @@ class OneBitLlamaForCausalLM(nn.Module):
             cache.length = past + S
             return logits
         h = self.model.embed_tokens(input_ids)
-        cos, sin = self._rope_tables(h.device, h.dtype)
+        cos, sin = self._rope_tables(h.device, h.dtype, past + S)
         for layer, kv in zip(self.model.layers, cache.layers):
             h = layer(h, cos, sin, kv, past)
         cache.length = past + S

@@ -326,3 +326,37 @@ def test_rows_glue_scaled_outputs_small_ragged_shapes():
                                       T, H, 1e-6, 1e-5, sp) != 0
     assert lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout0.data_ptr(), x0.data_ptr(), nul, nul, 1,
                                       T, H, 1e-6, 1e-5, sp) != 0
+
+
+@pytest.mark.parametrize("kind", ["linear", "dynamic", "none"])
+def test_rope_scaling_variants_match_reference(golden_dir, kind):
+    """The reference's RoPE scaling variants (modeling_bitllama.py:123-165: linear = positions / factor, dynamic NTK = base
+    rescaled once the sequence exceeds max_position_embeddings) and its on-demand growth of the rotary cache: a
+    24-token prompt on a model with max_position_embeddings = 16 (so "dynamic" rescales, twice more during the two
+    cached decode steps, exactly as the reference's stateful cache does), fp32 parameters, against logits recorded
+    from the reference model (tests/golden/gen_goldens_rope.py)."""
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, "model_rope.npz"))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    rs = None if kind == "none" else {"type": kind, "factor": 2.0}
+    cfg = OneBitLlamaConfig(rope_scaling=rs, **kw)
+    model = OneBitLlamaForCausalLM(cfg, torch.float32)
+    sd = {k: (v if v.dtype == torch.int8 else v.float()) for k, v in synthetic_state_dict(OneBitLlamaConfig(**kw), seed=7, dtype=torch.float16).items()}
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    ref = z["logits_" + kind]
+    cache = model.new_cache(1, 32)
+    got = [model(ids, cache).cpu().numpy()]
+    toks = z["greedy_" + kind]
+    for i in range(2):
+        got.append(model(torch.from_numpy(toks[:, i:i + 1]).to(dev), cache).cpu().numpy())
+    got = np.concatenate(got, axis=1)
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), np.abs(got - ref).max()
+    if kind != "none":                                       # and the variants really differ from the unscaled model
+        assert np.abs(z["logits_" + kind] - z["logits_none"]).max() > 50 * np.abs(got - ref).max()
+    with pytest.raises(ValueError):
+        OneBitLlamaConfig(rope_scaling={"type": "yarn", "factor": 2.0}, **kw)
+    with pytest.raises(ValueError):
+        OneBitLlamaConfig(rope_scaling={"type": "linear", "factor": 1}, **kw)
