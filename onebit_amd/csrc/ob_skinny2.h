@@ -1,21 +1,25 @@
 // Skinny 1-bit GEMM, second form: 2 <= T <= 32 tokens on PRE-SCALED activation rows a = fp16(x * h) (written by the
-// producers: onebit_rows_res_ln_rms / onebit_rows_swiglu with h_next, the batched attention kernel), the batched decode
-// step's four GEMMs per layer.
+// producers: onebit_rows_res_ln_rms / onebit_rows_swiglu with h_next, the batched attention kernel).  Used where it
+// measured faster than the first form (ob_skinny.h): ONE projection with ONE 512-weight chunk per wave (K <= 4096) -- the
+// batched decode step's o_proj (7.9 vs 10.6 us at 7B, 32 slots) and ONEBIT_FLAG_PRESCALED calls of short prompts.
 //
-// The first form (ob_skinny.h) walks K in 512-element phases through LDS with a workgroup barrier per phase: 215
-// instructions per wave and phase of which 68 expand signs, and a launch is 8 phases of ~2400 cycles whatever the
-// matrix pipe does.  This one is the decode GEMV (ob_decode.h) generalised to a tile of tokens:
-//   * persistent grid, one 512-thread workgroup per CU; workgroup b owns 16-row tiles b, b + G, ... of each projection;
-//   * its 8 waves split K in 512-weight chunks (wave w: chunks w, w + 8, ...): a lane's packed words go global ->
-//     VGPR -> MFMA A operand (one 16-byte non-temporal load per tile and chunk, all issued at kernel entry), NO LDS and
-//     NO barrier until the partial accumulators meet at the end;
-//   * the activations of a chunk are the B operands, held in registers for every row tile of the projection; they come
-//     from the L2-resident rows in whole 128-byte lines through a WAVE-PRIVATE LDS image (half a chunk at a time, no
-//     barrier: a wave's LDS operations are ordered), the next half-chunk's lines in flight under this one's MFMAs;
+// The first form walks K in 512-element phases through LDS with a workgroup barrier per phase (8 phases of ~2400 cycles
+// for K = 4096 whatever the matrix pipe does).  This one is the decode GEMV (ob_decode.h) generalised to a tile of tokens:
+//   * persistent grid, one 512-thread workgroup per CU; workgroup b owns 16-row tiles b, b + G, ... of the projection;
+//   * its 8 waves split K in 512-weight chunks (wave w: chunk w): a lane's packed words go global -> VGPR -> MFMA A
+//     operand (one 16-byte non-temporal load per tile, all issued at kernel entry), NO barrier until the partial
+//     accumulators meet at the end;
+//   * the activations of the chunk are the B operands, held in registers for every row tile; they come from the
+//     L2-resident rows in whole 128-byte lines through a WAVE-PRIVATE LDS image (half a chunk at a time, no barrier: a
+//     wave's LDS operations are ordered), the second half-chunk's lines in flight under the first one's MFMAs;
 //   * with the scaling done by the producer the only VALU work is the sign expansion (17 instructions per 4 MFMAs at
-//     T = 32): matrix pipe and VALU are balanced, two waves per SIMD overlap one's expansion with the other's MFMAs.
-// Epilogue: partial accumulators of the 8 waves through LDS (MT * TT KB per wave), fixed-order fp32 sum, fp16(z) * g
-// (bitnet.py:115-116), optional per-token LayerNorm tile partials for the consumer (as ob_skinny.h).
+//     T = 32).
+// The template is general in (projections, tile slots, chunks per wave); with several projections or chunks per wave a
+// workgroup pulls one [T, 512-chunk] slab per (projection, chunk) with half a chunk of lookahead and every projection
+// has its OWN scaled rows -- q|k|v 22.4, gate|up 18.1, down 16.7 us against 14.8 / 14.8 / 10.6 for the first form -- so
+// only the single-set instances are built (onebit_hip.hip, ob_launch_skinny2).
+// Epilogue: partial accumulators of the 8 waves through LDS, fixed-order fp32 sum, fp16(z) * g (bitnet.py:115-116),
+// optional per-token LayerNorm tile partials for the consumer (as ob_skinny.h).
 #pragma once
 #include "ob_decode.h"
 #include "ob_skinny.h"
