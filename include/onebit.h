@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 5
+#define ONEBIT_ABI_VERSION 6
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -285,6 +285,11 @@ typedef struct onebit_batch_state {
      * workgroups combine them instead of re-reducing the rows (same values up to fp32 rounding of
      * mean / rstd).  NULL: recompute per workgroup.                                                 */
     float *qkv_stats;
+    /* optional: fp16 [3, B, hidden] scratch.  With it the row kernels write the pre-scaled rows fp16(x * input_factor)
+     * of every consuming projection (the rounding of bitnet.py:113 done once by the producer) and all seven projections
+     * of a layer take the LDS-DMA skinny GEMM (same sums, fp32 accumulation order differs).  NULL: the projections
+     * scale x themselves.                                                                                          */
+    void *x_scaled;
 } onebit_batch_state_t;
 
 size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);

@@ -38,12 +38,19 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     const int64_t row = (int64_t)blockIdx.x * H;
     const _Float16 *src = EMBED ? A.embed + (int64_t)A.tokens[blockIdx.x] * H : A.hres_in + row;
     ob_half8 hv[NV], uv[NV];
+    // the vectors of the LAST phase (RMSNorm weight, the consumers' input_factor) are requested here, with the rows: asked
+    // for after the two block reductions, their L2 round trip was the tail of every launch
+    ob_half8 wv[NV], hn[3][NV];
     bool valid[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         valid[v] = base < H;
         hv[v] = *reinterpret_cast<const ob_half8 *>(src + (valid[v] ? base : 0));
+        wv[v] = *reinterpret_cast<const ob_half8 *>(A.rms_w + (valid[v] ? base : 0));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < A.n_scaled) hn[j][v] = *reinterpret_cast<const ob_half8 *>(A.h_next[j] + (valid[v] ? base : 0));
         if (!EMBED) {
             const int b0 = valid[v] ? base : 0;
             if (A.u_prev) {
@@ -99,14 +106,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         if (valid[v]) {
-            const ob_half8 w = *reinterpret_cast<const ob_half8 *>(A.rms_w + base);
             ob_half8 t;
 #pragma unroll
             for (int i = 0; i < 8; ++i) t[i] = (_Float16)__builtin_fmaf((float)hv[v][i], rs, 0.0f);
-            const ob_half8 xv = w * t;
+            const ob_half8 xv = wv[v] * t;
             if (A.x) *reinterpret_cast<ob_half8 *>(A.x + row + base) = xv;
-            for (int j = 0; j < A.n_scaled; ++j)
-                *reinterpret_cast<ob_half8 *>(A.x_scaled[j] + row + base) = xv * *reinterpret_cast<const ob_half8 *>(A.h_next[j] + base);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < A.n_scaled) *reinterpret_cast<ob_half8 *>(A.x_scaled[j] + row + base) = xv * hn[j][v];
             *reinterpret_cast<ob_half8 *>(A.hres_out + row + base) = hv[v];
         }
     }
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, I = A.I;
     const int64_t row = (int64_t)blockIdx.x * I;
-    ob_half8 g8[NV], u8[NV];
+    ob_half8 g8[NV], u8[NV], hn[NV];
     bool valid[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
         valid[v] = base < I;
         g8[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + row + (valid[v] ? base : 0));
         u8[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + row + (valid[v] ? base : 0));
+        if (A.h_next) hn[v] = *reinterpret_cast<const ob_half8 *>(A.h_next + (valid[v] ? base : 0));   // (used after the reduction)
     }
     float mg, rg, mu, ru;
     if (A.ext) {                                            // uniform per launch
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
                 sg[i] = (_Float16)__builtin_fmaf((float)gh, __builtin_amdgcn_rcpf(1.0f + e), 0.0f);
             }
             ob_half8 av = sg * up;                                               // act_fn(gate) * up -> fp16
-            if (A.h_next) av = av * *reinterpret_cast<const ob_half8 *>(A.h_next + base);       // fp16(act * h), bitnet.py:113
+            if (A.h_next) av = av * hn[v];                                                      // fp16(act * h), bitnet.py:113
             *reinterpret_cast<ob_half8 *>(A.act + row + base) = av;
         }
     }

@@ -15,6 +15,7 @@
 #include "ob_gemm2.h"
 #include "ob_skinny.h"
 #include "ob_skinny2.h"
+#include "ob_skinny3.h"
 #include "ob_batch.h"
 #include "ob_train.h"
 #include "ob_flash.h"
@@ -295,6 +296,11 @@ struct ObGemvArgs;
 struct ObSk2Args;
 static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool dry);
 static bool ob_skinny2_shape_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K);
+struct ObSk3Args;
+template <bool PARTIAL> static bool ob_launch_skinny3(const ObSk3Args &a, int grid, int rnt, hipStream_t s);
+static bool ob_skinny3_shape_ok(const void *packed, int64_t ldw_bytes, const void *a, int64_t lda, int64_t T, int64_t K, int64_t N);
+static int ob_skinny3_rnt(int64_t N);
+static int ob_skinny3_pick_rnt(const int64_t *N, int np, int copies);
 static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s);
 static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const void *x, const void *h, const void *g,
                                 void *u, int64_t K, int64_t N, hipStream_t s);
@@ -385,15 +391,30 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
             if (rc) return rc;
         } else if (prescaled && !ob_gemm3_ok(T, K, N)) {
-            // 2 <= T <= 32 on producer-scaled rows: the second-form skinny GEMM
-            ObSk2Args a = {};
-            a.lda = K; a.T = (int)T; a.K = (int)K;
-            a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, (int)N};
-            a.p[1] = a.p[0]; a.p[2] = a.p[0];
-            if (!ob_skinny2_shape_ok(packed, ldw_bytes, T, K) || !ob_launch_skinny2(a, 1, s, false))
-                return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
-            rc = ob_launch_status("linear_forward(skinny2)");
-            if (rc) return rc;
+            // 2 <= T <= 64 on producer-scaled rows: the LDS-DMA skinny GEMM (ob_skinny3.h); OB_SKINNY3=0: the second form
+            // (ob_skinny2.h) where it has an instance
+            static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
+            if (sk3_env && ob_skinny3_shape_ok(packed, ldw_bytes, x, K, T, K, N)) {
+                const int rnt = ob_skinny3_rnt(N);
+                ObSk3Args a = {};
+                a.lda = K; a.T = (int)T;
+                a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, nullptr,
+                          (int)N, (int)K, (int)((N + 16 * rnt - 1) / (16 * rnt))};
+                a.p[1] = a.p[0]; a.p[2] = a.p[0];
+                if (!ob_launch_skinny3<false>(a, a.p[0].wg_end, rnt, s))
+                    return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
+                rc = ob_launch_status("linear_forward(skinny3)");
+                if (rc) return rc;
+            } else {
+                ObSk2Args a = {};
+                a.lda = K; a.T = (int)T; a.K = (int)K;
+                a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, (int)N};
+                a.p[1] = a.p[0]; a.p[2] = a.p[0];
+                if (!ob_skinny2_shape_ok(packed, ldw_bytes, T, K) || !ob_launch_skinny2(a, 1, s, false))
+                    return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
+                rc = ob_launch_status("linear_forward(skinny2)");
+                if (rc) return rc;
+            }
         } else if (prescaled || (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
                                  ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32))) {
             // pre-scale once (the fp16 rounding of bitnet.py:113) -- unless the producer of x already did
@@ -754,7 +775,10 @@ extern "C" int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int d
 {
     if (dtype != ONEBIT_F16 || T <= 0 || K <= 0 || N <= 0 || K % 32 != 0) return 0;
     if (ob_gemm3_ok(T, K, N)) return 1;
-    // 2 <= T <= 32: the second-form skinny GEMM (ob_skinny2.h) consumes pre-scaled rows too, where an instance exists
+    // 2 <= T <= 64: the LDS-DMA skinny GEMM (ob_skinny3.h) consumes pre-scaled rows too (OB_SKINNY3=0: the second form,
+    // ob_skinny2.h, where it has an instance)
+    static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
+    if (sk3_env && T >= 2 && T <= 64 && K % 128 == 0 && K >= 512 && T * K * 2 < ((int64_t)1 << 32)) return 1;
     if (T >= 2 && T <= 32 && K % 128 == 0 && K >= 512 && K <= 16384) {
         ObSk2Args a = {};
         a.T = (int)T; a.K = (int)K; a.p[0].N = a.p[1].N = a.p[2].N = (int)N;
@@ -879,6 +903,75 @@ static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool
     return hit;
 }
 
+// ---- skinny GEMM, LDS-DMA form (ob_skinny3.h): pre-scaled rows, 2 <= T <= 64, 16 * rnt rows per 4-wave workgroup
+template <bool PARTIAL, int RT, int RNT, int NW>
+static void ob_launch_sk3_t(const ObSk3Args &a_in, int grid, hipStream_t s)
+{
+    ObSk3Args a = a_in;
+#ifdef OB_PROFILE_STAMPS
+    a.dbg = ob_dbg_buffer();
+#endif
+    // ring depth per wave: what fits 160 KB of LDS with NW private rings (a piece is 5 / 9 / 17 KB at 16 / 32 / 64 tokens)
+#ifndef OB_SK3_NBUF4
+#define OB_SK3_NBUF4 2
+#endif
+    constexpr int NBUF = RT == 1 ? 3 : (NW == 4 && RT == 2 ? OB_SK3_NBUF4 : 2);
+    constexpr int lds = OB_SK3_LDS(RT, RNT, NBUF, NW);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_skinny3_kernel<PARTIAL, RT, RNT, NBUF, NW>, attr_set, lds);
+    hipLaunchKernelGGL((ob_skinny3_kernel<PARTIAL, RT, RNT, NBUF, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+}
+static bool ob_skinny3_shape_ok(const void *packed, int64_t ldw_bytes, const void *a, int64_t lda, int64_t T, int64_t K, int64_t N)
+{
+    return T >= 2 && T <= 64 && K % 128 == 0 && K >= 512 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && ob_aligned(a, 16) &&
+           lda % 8 == 0 && T * lda * 2 < ((int64_t)1 << 32) && N * ldw_bytes < ((int64_t)1 << 32);
+}
+// 16-row tiles per workgroup: the smallest count whose grid fits one round of workgroups (one 144 KB workgroup per CU);
+// `copies` = K-slices per projection (split-K launches)
+static int ob_skinny3_pick_rnt(const int64_t *N, int np, int copies)
+{
+    static const int env = getenv("OB_SK3_RNT") ? atoi(getenv("OB_SK3_RNT")) : 0;      // A/B switch
+    if (env == 1 || env == 2 || env == 3 || env == 4 || env == 6 || env == 8) return env;
+    static const int cand[6] = {1, 2, 3, 4, 6, 8};
+    for (int c = 0; c < 6; ++c) {
+        int64_t wgs = 0;
+        for (int i = 0; i < np; ++i) wgs += (N[i] + 16 * cand[c] - 1) / (16 * cand[c]);
+        if (wgs * copies <= ob_cu_count()) return cand[c];
+    }
+    return 4;
+}
+static int ob_skinny3_rnt(int64_t N) { return ob_skinny3_pick_rnt(&N, 1, 1); }
+// 8 waves (K split eight ways, two waves per SIMD: one wave's transfers wait while the other multiplies) wherever the
+// private rings fit the LDS; 64-token tiles: 4 waves.  OB_SK3_NW=4: A/B switch for the fp16-output instances.
+template <bool PARTIAL, int RT, int RNT>
+static void ob_launch_sk3_nw(const ObSk3Args &a, int grid, hipStream_t s)
+{
+    if constexpr (RT == 4) ob_launch_sk3_t<PARTIAL, RT, RNT, 4>(a, grid, s);
+    else if constexpr (PARTIAL) ob_launch_sk3_t<PARTIAL, RT, RNT, 8>(a, grid, s);
+    else {
+        static const int nw_env = getenv("OB_SK3_NW") ? atoi(getenv("OB_SK3_NW")) : 8;
+        if (nw_env == 4) ob_launch_sk3_t<PARTIAL, RT, RNT, 4>(a, grid, s);
+        else ob_launch_sk3_t<PARTIAL, RT, RNT, 8>(a, grid, s);
+    }
+}
+template <bool PARTIAL>
+static bool ob_launch_skinny3(const ObSk3Args &a, int grid, int rnt, hipStream_t s)
+{
+    const int RTv = a.T <= 16 ? 1 : (a.T <= 32 ? 2 : 4);
+    bool hit = false;
+#define OB_SK3(RT_, RNT_)                                                                 \
+    if (!hit && RTv == RT_ && rnt == RNT_) {                                              \
+        hit = true;                                                                       \
+        ob_launch_sk3_nw<PARTIAL, RT_, RNT_>(a, grid, s);                                 \
+    }
+    OB_SK3(1, 1) OB_SK3(1, 2) OB_SK3(1, 3) OB_SK3(1, 4) OB_SK3(1, 6) OB_SK3(1, 8)
+    OB_SK3(2, 1) OB_SK3(2, 2) OB_SK3(2, 3) OB_SK3(2, 4) OB_SK3(2, 6) OB_SK3(2, 8)
+    OB_SK3(4, 1) OB_SK3(4, 2) OB_SK3(4, 3) OB_SK3(4, 4) OB_SK3(4, 6)
+#undef OB_SK3
+    return hit;
+}
+
 extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
 {
     if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
@@ -997,6 +1090,42 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
                 ob_launch_skinny2(ka, 1, s, true);
     }
     if (o_sk2) splitk_o = false;
+    // Every projection through the LDS-DMA skinny GEMM (ob_skinny3.h) when the state has room for the consumers' pre-scaled
+    // rows (x_scaled: 3 x [B, hidden]): the row kernels write fp16(x * h_p) per consuming projection (the rounding of
+    // bitnet.py:113 done by the producer), attention and SwiGLU scale their outputs for o_proj / down_proj, down_proj runs
+    // as two K-slices whose fp32 partial sums the next norm kernel adds.  OB_SKINNY3=0: the first-form kernels above.
+    static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
+    _Float16 *xs[3] = {(_Float16 *)st->x_scaled, (_Float16 *)st->x_scaled + (size_t)B * H, (_Float16 *)st->x_scaled + (size_t)2 * B * H};
+    bool sk3 = sk3_env && st->x_scaled && ob_aligned(st->x_scaled, 16) && NQ == H && H % 128 == 0 && I % 256 == 0 && (int64_t)I * 2 >= (int64_t)H * 4;
+    for (int l = 0; sk3 && l < m->n_layers; ++l) {
+        const onebit_layer_t &L = m->layers[l];
+        const onebit_proj_t *pp[7] = {&L.q, &L.k, &L.v, &L.o, &L.gate, &L.up, &L.down};
+        const int64_t kk[7] = {H, H, H, NQ, H, H, I}, nn[7] = {NQ, NK, NK, H, I, I, H};
+        for (int i = 0; sk3 && i < 7; ++i) {
+            const onebit_proj_t &p = *pp[i];
+            sk3 = p.weight && p.input_factor && p.weight_scale && p.K == kk[i] && p.N == nn[i] &&
+                  ob_skinny3_shape_ok(p.weight, p.ldw_bytes, xs[0], kk[i], B, i == 6 ? kk[i] / 2 : kk[i], nn[i]);
+        }
+    }
+    const bool down_parts = sk3 || splitk_down;
+    struct A3 { const _Float16 *a[3]; };
+    auto gemm_sk3 = [&](P3 ps, U3 us, S3 ss, A3 as, int np, int64_t K, const char *name) -> int {
+        int64_t nn[3] = {0, 0, 0};
+        for (int i = 0; i < np; ++i) nn[i] = ps.p[i]->N;
+        const int rnt = ob_skinny3_pick_rnt(nn, np, 1);
+        ObSk3Args ka = {};
+        int wgs = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int j = i < np ? i : np - 1;
+            const onebit_proj_t &p = *ps.p[j];
+            if (i < np) wgs += (int)((p.N + 16 * rnt - 1) / (16 * rnt));
+            ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.weight_scale, as.a[j],
+                       (_Float16 *)us.u[j], nullptr, ss.s[j], (int)p.N, (int)K, wgs};
+        }
+        ka.lda = K; ka.T = B;
+        if (!ob_launch_skinny3<false>(ka, wgs, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
+        return ob_launch_status("decode_step_batched(gemm)");
+    };
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -1004,10 +1133,15 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm
         ObBNormArgs na = {};
         na.embed = (const _Float16 *)m->embed; na.tokens = st->tokens; na.hres_in = hA;
-        if (splitk_down && l > 0) { na.u_prev = nullptr; na.z0 = zs0; na.z1 = zs1; na.g_prev = (const _Float16 *)m->layers[l - 1].down.weight_scale; }
+        if (down_parts && l > 0) { na.u_prev = nullptr; na.z0 = zs0; na.z1 = zs1; na.g_prev = (const _Float16 *)m->layers[l - 1].down.weight_scale; }
         else na.u_prev = (const _Float16 *)st->u_down;
         na.rms_w = (const _Float16 *)L.input_layernorm_w; na.hres_out = hB; na.x = (_Float16 *)st->x; na.H = H;
         na.rms_eps = m->rms_eps; na.ln_eps = m->ln_eps;
+        if (sk3) {
+            na.x = nullptr; na.n_scaled = 3;
+            na.h_next[0] = (const _Float16 *)L.q.input_factor; na.h_next[1] = (const _Float16 *)L.k.input_factor; na.h_next[2] = (const _Float16 *)L.v.input_factor;
+            na.x_scaled[0] = xs[0]; na.x_scaled[1] = xs[1]; na.x_scaled[2] = xs[2];
+        }
         if (l == 0) OB_LAUNCH_NORM(true, H, dim3(B), s, na);
         else OB_LAUNCH_NORM(false, H, dim3(B), s, na);
         if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
@@ -1019,7 +1153,10 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
             qs.s[0] = st->qkv_stats; qs.s[1] = st->qkv_stats + (size_t)B * fq; qs.s[2] = st->qkv_stats + (size_t)B * (fq + fk);
         }
-        if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, qs, 3, st->x, H, "qkv"))) return rc;
+        if (sk3) {
+            if ((rc = gemm_sk3({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, qs, {xs[0], xs[1], xs[2]}, 3, H, "qkv"))) return rc;
+            stats_written = qs.s[0] != nullptr;
+        } else if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, qs, 3, st->x, H, "qkv"))) return rc;
         const bool attn_pst = stats_written;
         // 3. attention per (head, slot)
         ObAttnArgs at = {};
@@ -1033,14 +1170,19 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
-        if (o_sk2) at.h_next = (const _Float16 *)L.o.input_factor;
+        static const int sk3_o = getenv("OB_SK3_O") ? atoi(getenv("OB_SK3_O")) : 1;          // A/B: o_proj through ob_skinny3 (1) or ob_skinny2 (0)
+        const bool o_sk3 = sk3 && (sk3_o || !o_sk2);
+        if (o_sk2 || o_sk3) at.h_next = (const _Float16 *)L.o.input_factor;
         if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if (o_sk2) {
+        if (o_sk3) {
+            if ((rc = gemm_sk3({&L.o, nullptr, nullptr}, {st->u_o, nullptr, nullptr}, {{nullptr, nullptr, nullptr}},
+                               {(const _Float16 *)st->attn_out, nullptr, nullptr}, 1, NQ, "o"))) return rc;
+        } else if (o_sk2) {
             ObSk2Args ka = {};
             ka.lda = NQ; ka.T = B; ka.K = NQ;
             ka.p[0] = {(const uint32_t *)L.o.weight, (long long)(L.o.ldw_bytes / 4), (const _Float16 *)L.o.weight_scale,
@@ -1055,24 +1197,48 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ObBNormArgs nb = na;
         nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
-        if (splitk_o) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; } nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
+        if (splitk_o && !o_sk3) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
+        nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
+        if (sk3) {
+            nb.x = nullptr; nb.n_scaled = 2; nb.h_next[2] = nullptr; nb.x_scaled[2] = nullptr;
+            nb.h_next[0] = (const _Float16 *)L.gate.input_factor; nb.h_next[1] = (const _Float16 *)L.up.input_factor;
+            nb.x_scaled[0] = xs[0]; nb.x_scaled[1] = xs[1];
+        }
         OB_LAUNCH_NORM(false, H, dim3(B), s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
-        if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
-        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr, nullptr};
+        if (sk3) {
+            if ((rc = gemm_sk3({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {{nullptr, nullptr, nullptr}}, {xs[0], xs[1], nullptr}, 2, H, "gate|up"))) return rc;
+        } else if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
+        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps,
+                            sk3 ? (const _Float16 *)L.down.input_factor : nullptr, nullptr};
         OB_LAUNCH_SWIGLU(I, dim3(B), s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges
         //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
-        if (splitk_down) {
+        if (sk3) {
+            // two K-slices of the pre-scaled SwiGLU rows, fp32 partial sums (u_gate / u_up are free: SwiGLU has consumed them)
+            const int Kh = I / 2;
+            const int64_t nh[1] = {H};
+            const int rnt = ob_skinny3_pick_rnt(nh, 1, 2);
+            const int wg1 = (H + 16 * rnt - 1) / (16 * rnt);
+            ObSk3Args ka = {};
+            for (int i = 0; i < 3; ++i) {
+                const int j = i < 2 ? i : 1;
+                ka.p[i] = {(const uint32_t *)L.down.weight + j * (Kh / 32), (long long)(L.down.ldw_bytes / 4), nullptr,
+                           (const _Float16 *)st->act + j * Kh, nullptr, j == 0 ? zs0 : zs1, nullptr, H, Kh, wg1 * (j + 1)};
+            }
+            ka.lda = I; ka.T = B;
+            if (!ob_launch_skinny3<true>(ka, 2 * wg1, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for down");
+            if ((rc = ob_launch_status("decode_step_batched(down)"))) return rc;
+        } else if (splitk_down) {
             if ((rc = gemm_splitk2(L.down, st->act, I, zs0, zs1, "down"))) return rc;
         } else if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
     }
     // final: residual + LayerNorm(u_down) + final RMSNorm -> x
     ObBNormArgs nf = {};
     nf.hres_in = hA; nf.rms_w = (const _Float16 *)m->final_norm_w; nf.hres_out = hB;
-    if (splitk_down) { nf.u_prev = nullptr; nf.z0 = zs0; nf.z1 = zs1; nf.g_prev = (const _Float16 *)m->layers[m->n_layers - 1].down.weight_scale; }
+    if (down_parts) { nf.u_prev = nullptr; nf.z0 = zs0; nf.z1 = zs1; nf.g_prev = (const _Float16 *)m->layers[m->n_layers - 1].down.weight_scale; }
     else nf.u_prev = (const _Float16 *)st->u_down;
     nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
     OB_LAUNCH_NORM(false, H, dim3(B), s, nf);

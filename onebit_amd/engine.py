@@ -54,7 +54,8 @@ class _BatchState(ctypes.Structure):
     _fields_ = [("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
-                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp)]
+                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp),
+                ("x_scaled", _vp)]
 
 
 class _FusedIn(ctypes.Structure):
@@ -302,7 +303,7 @@ class BatchedDecodeStep:
     ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
 
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
-                 keep_logits: bool = False, producer_stats: bool = True):
+                 keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True):
         cfg = model.config
         p = model.lm_head.weight
         if not p.is_cuda:
@@ -345,7 +346,11 @@ class BatchedDecodeStep:
         self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
-                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None)
+                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None, None)
+        # room for the consumers' pre-scaled rows fp16(x * input_factor): the projections then take the LDS-DMA skinny GEMM
+        if prescaled_rows:
+            self._x_scaled = torch.zeros(3, batch, H, dtype=f16, device=dev)
+            self._state.x_scaled = self._x_scaled.data_ptr()
         # scratch for the q|k|v LayerNorm partials (published by the GEMM, combined by the attention workgroups)
         if producer_stats:
             nst = int(self.lib.onebit_batch_stats_floats(ctypes.byref(self._model), batch))

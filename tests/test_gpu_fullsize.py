@@ -313,18 +313,19 @@ def test_prescaled_route_is_bit_identical_at_full_size():
     assert torch.equal(act_s, act * hd)
     # a shape on another kernel route refuses the flag
     small, *_ = _mk(512, 64, 5, dev)
-    assert small.prescaled_ok(8)                                    # 2 <= T <= 32: the second-form skinny GEMM takes scaled rows
-    assert not small.prescaled_ok(40)                               # 40 tokens: neither that nor the LDS-DMA GEMM
+    assert small.prescaled_ok(8) and small.prescaled_ok(40)         # 2 <= T <= 64: the LDS-DMA skinny GEMM takes scaled rows
+    assert not small.prescaled_ok(100)                              # 100 tokens: neither that nor the LDS-DMA prefill GEMM
     with pytest.raises(Exception):
-        small.pre_layernorm_prescaled(torch.zeros(40, 512, dtype=torch.float16, device=dev))
+        small.pre_layernorm_prescaled(torch.zeros(100, 512, dtype=torch.float16, device=dev))
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (1024, 528), (512, 48)])
-@pytest.mark.parametrize("T", [2, 7, 16, 17, 32])
-def test_second_form_skinny_gemm_on_prescaled_rows_vs_oracle(coracle, K, N, T):
-    """ob_skinny2.h (2 <= T <= 32 tokens on producer-scaled rows fp16(x * h), one 512-weight chunk per wave: the batched
-    step's o_proj and the ONEBIT_FLAG_PRESCALED route of short prompts) against the oracle's complete layer: u within
-    2 fp16 ulps, and equal to the first form up to the fp32 summation order."""
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (11008, 4096), (1024, 528), (512, 48), (640, 1000)])
+@pytest.mark.parametrize("T", [2, 7, 16, 17, 32, 33, 64])
+def test_skinny_gemm_on_prescaled_rows_vs_oracle(coracle, K, N, T):
+    """ob_skinny3.h (2 <= T <= 64 tokens on producer-scaled rows fp16(x * h), global -> LDS by DMA, waves split K in private
+    rings: the batched step's projections and the ONEBIT_FLAG_PRESCALED route of short prompts) against the oracle's
+    complete layer: u within 2 fp16 ulps, and equal to the first form up to the fp32 summation order.  Shapes cover every
+    row-tile count per workgroup (1 .. 8), ragged N (528, 1000, 48) and piece counts that do not divide by the wave count."""
     dev = torch.device("cuda:0")
     m, packed, h, g = _mk(K, N, 1000 + K + N, dev)
     assert m.prescaled_ok(T)
@@ -337,4 +338,3 @@ def test_second_form_skinny_gemm_on_prescaled_rows_vs_oracle(coracle, K, N, T):
     for t in range(T):
         _check_u(u2[t], u_ref[t], "K=%d N=%d T=%d row %d" % (K, N, T, t))
     assert (u1 != u2).mean() <= 0.02
-    assert not m.prescaled_ok(33) or K * N >= 4096 * 4096        # beyond 32 tokens only the LDS-DMA GEMM takes pre-scaled rows

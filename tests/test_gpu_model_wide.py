@@ -111,8 +111,10 @@ def test_decode_engine(wide, use_graph):
         assert np.abs(lg - z["decode_logits_f32"][0, i]).max() <= tol
 
 
-def test_batched_decode_step_32_slots(wide):
-    """32 sequences: batched prefill through the module path (checked against the reference's batched call), then
+@pytest.mark.parametrize("prescaled_rows", [True, False])
+def test_batched_decode_step_32_slots(wide, prescaled_rows):
+    """(prescaled_rows: the row kernels write fp16(x * input_factor) per consumer and every projection takes the LDS-DMA
+    skinny GEMM, ob_skinny3.h; without: the first-form kernels scale x themselves.)  32 sequences: batched prefill through the module path (checked against the reference's batched call), then
     three native batched steps (onebit_decode_step_batched: skinny 1-bit GEMMs, row kernels, per-slot attention,
     batched lm_head) teacher-forced with the reference's tokens -- logits of every slot against the reference."""
     from onebit_amd.engine import BatchedDecodeStep
@@ -126,7 +128,7 @@ def test_batched_decode_step_32_slots(wide):
     ref16, ref32 = z["batch_logits_f16"], z["batch_logits_f32"]
     tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
     assert np.abs(lg - ref16[:, 0]).max() <= tol
-    step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True)
+    step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True, prescaled_rows=prescaled_rows)
     toks = z["batch_greedy_f16"]
     for i in range(3):
         step.tokens.copy_(torch.from_numpy(toks[:, i].astype(np.int32)))

@@ -1,5 +1,5 @@
-"""Per-launch time of the two skinny 1-bit GEMM forms (ob_skinny.h on x with the scaling fused; ob_skinny2.h on
-producer-scaled rows) at the LLaMA-7B projection shapes, T tokens, one projection per launch, graph-replayed chains
+"""Per-launch time of the skinny 1-bit GEMM forms (ob_skinny.h on x with the scaling fused; the pre-scaled route on
+producer-scaled rows: ob_skinny3.h, or ob_skinny2.h with OB_SKINNY3=0) at the LLaMA-7B projection shapes, T tokens, one projection per launch, graph-replayed chains
 over 32 distinct weight sets (like bench.py's roofline chains).  Usage: python tools/skinny_cmp.py [T]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,6 +33,12 @@ for name, K, N in (("q/o 4096->4096", 4096, 4096), ("gate 4096->11008", 4096, 11
     ok = mods[0].prescaled_ok(T)
     t1 = chain_us(lambda m: m.pre_layernorm(x), mods)
     t2 = chain_us(lambda m: m.pre_layernorm_prescaled(a), mods) if ok else float("nan")
-    same = bool(torch.equal(mods[0].pre_layernorm(x), mods[0].pre_layernorm_prescaled(a))) if ok else None
-    print("T=%d %-18s form 1 %6.2f us   form 2 %6.2f us   bit-identical %s" % (T, name, t1, t2, same), flush=True)
+    u1 = mods[0].pre_layernorm(x).float()
+    u2 = mods[0].pre_layernorm_prescaled(a).float() if ok else u1
+    # fp32 reference of the same op: fp16(fp16(sign(W) . a) * g)
+    wb = mods[0].weight.data.view(torch.uint8)
+    sg = 1.0 - 2.0 * ((wb.unsqueeze(-1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(N, K).float()
+    ref = ((a.float() @ sg.t()).half().float() * mods[0].weight_scale.data.float()).half().float()
+    print("T=%d %-18s form 1 %6.2f us   pre-scaled %6.2f us   max |form1 - prescaled| %.3g   max |prescaled - fp32 ref| %.3g  (max |ref| %.3g)"
+          % (T, name, t1, t2, (u1 - u2).abs().max().item(), (u2 - ref).abs().max().item(), ref.abs().max().item()), flush=True)
     del mods
