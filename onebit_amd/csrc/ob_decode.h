@@ -1066,6 +1066,16 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
     const bool dok = 8 * ds < D;
     const int dcl = dok ? 8 * ds : 0;
     ob_half8 kreg[NI], vreg[NI];
+    // everything that does not depend on the position is requested before the position is read (batched step: the
+    // position, then the K / V rows, then the rest were three dependent round trips)
+    ObTileStatsRt tq, tk, tv;
+    if (PST) { ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane); }
+    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
+    const int half = D >> 1;
+    const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
+    const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
+    const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
+    const _Float16 hnx = A.h_next ? A.h_next[head * D + dq] : (_Float16)1;
     int pos_early = 0;
     if (!BLIND) {
         pos_early = *A.pos;
@@ -1085,13 +1095,6 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
     if (pos < 0 || pos >= A.max_len) return;      // idle slot, or a step past the cache (host error: never write or
                                                   // read beyond the allocation); uniform, before any barrier
     const int L = pos + 1;
-    ObTileStatsRt tq, tk, tv;
-    if (PST) { ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane); }
-    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
-    const int half = D >> 1;
-    const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
-    const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
-    const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
     const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
     __builtin_amdgcn_sched_barrier(0);
 
@@ -1264,7 +1267,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
 #pragma unroll
         for (int w = 0; w < NWV; ++w) acc += po[w * 128 + tid];
         _Float16 oh = (_Float16)acc;
-        if (A.h_next) oh = oh * A.h_next[head * D + tid];
+        if (A.h_next) oh = oh * hnx;
         A.out[head * D + tid] = oh;
     }
 }

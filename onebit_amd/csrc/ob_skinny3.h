@@ -179,6 +179,16 @@ __global__ __launch_bounds__(64 * NW) void ob_skinny3_kernel(const ObSk3Args A)
         if (i == 3) OB_SK_STAMP(6);
     }
     OB_SK_STAMP(7);
+    // weight_scale of this thread's first output slot, requested before the barriers (its L2 / HBM round trip would
+    // otherwise follow them)
+    constexpr int NSLOT = RNT * RT * 64;
+    const _Float16 *__restrict__ g = P.g;
+    const bool gvec = !PARTIAL && (N & 3) == 0 && (reinterpret_cast<size_t>(g) & 7) == 0;
+    ob_half4 g4p = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+    if (gvec && tid < NSLOT) {
+        const int nb0 = n0 + ((tid >> 6) / RT) * 16 + 4 * ((tid & 63) >> 4);
+        if (nb0 + 3 < N) g4p = *reinterpret_cast<const ob_half4 *>(g + nb0);
+    }
     __syncthreads();                            // every wave is done with its ring: the memory becomes the reduction buffer
 
     // the waves' partial accumulators meet in LDS: [wave][rn][rt][lane] float4; output slot (rn, rt, lane) is summed by one thread
@@ -189,8 +199,6 @@ __global__ __launch_bounds__(64 * NW) void ob_skinny3_kernel(const ObSk3Args A)
         for (int rt = 0; rt < RT; ++rt) zr[((wave * RNT + rn) * RT + rt) * 64 + lane] = acc[rn][rt];
     __syncthreads();
     OB_SK_STAMP(8);
-    constexpr int NSLOT = RNT * RT * 64;
-    const _Float16 *__restrict__ g = P.g;
     for (int slot = tid; slot < NSLOT; slot += 64 * NW) {                              // (uniform per wave: NSLOT % 64 == 0)
         const int sl = slot & 63, rt = (slot >> 6) % RT, rn = (slot >> 6) / RT;
         ob_float4 z = zr[((0 * RNT + rn) * RT + rt) * 64 + sl];
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void ob_skinny3_kernel(const ObSk3Args A)
         _Float16 o[4];
         float sm = 0.f;
         ob_half4 g4;
-        if (nb + 3 < N && (N & 3) == 0 && (reinterpret_cast<size_t>(g) & 7) == 0) g4 = *reinterpret_cast<const ob_half4 *>(g + nb);
+        if (gvec && nb + 3 < N) g4 = slot == tid ? g4p : *reinterpret_cast<const ob_half4 *>(g + nb);
         else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) g4[i] = g[min(nb + i, N - 1)];
