@@ -987,7 +987,7 @@ struct ObAttnArgs {
     long long slot_stride;               // elements between the caches of consecutive slots (blockIdx.y); rows of
                                          // u_q / u_k / u_v / out are consecutive per slot
     const _Float16 *h_next;              // optional [H * D]: out <- fp16(out * h_next), o_proj's input scaling (bitnet.py:113)
-                                         // for a consumer that takes pre-scaled rows (batched step, ob_skinny2.h)
+                                         // for a consumer that takes pre-scaled rows (batched step, ob_skinny3.h)
 };
 
 // Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and

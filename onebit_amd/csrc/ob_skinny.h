@@ -52,9 +52,9 @@ struct ObSkinnyArgs {
 #define OB_SKINNY_PK(RT_) ((RT_) >= 4 ? 512 : OB_SKINNY_PK12)
 #define OB_SKINNY_PKT(RT_) (OB_SKINNY_PK(RT_) * (RT_))
 #define OB_SKINNY_LDS(RT_) OB_SKINNY_LDS2(RT_, 4)
-// RNT = 16-row tiles per workgroup: 4 (64 rows), or 8 (128 rows) for the wide layers of the batched step --
-// what these launches move is the [T, K] activation block, once per workgroup out of L2 (the slope of the
-// T = 16 / 32 / 64 timings: ~7 TB/s chip-wide); twice the rows per workgroup is half of that traffic.
+// RNT = 16-row tiles per workgroup: 4 (64 rows), or 8 (128 rows: OB_SKINNY_WIDE=1, measured slower).  (What bounds
+// this form is its staging instruction stream between two barriers per phase, not the L2 -- tools/l2_rate_probe.hip;
+// ob_skinny3.h is the form without either, for producer-scaled rows.)
 #define OB_SKINNY_LDS2(RT_, RNT_) ((size_t)2 * 16 * (RT_) * (OB_SKINNY_PK(RT_) + 8) * 2 + (size_t)2 * 16 * (RNT_) * (OB_SKINNY_PK(RT_) / 32 + 1) * 4)
 
 template <bool PARTIAL, int RT, int RNT = 4>

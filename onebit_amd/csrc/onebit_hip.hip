@@ -14,7 +14,6 @@
 #include "ob_gemm.h"
 #include "ob_gemm2.h"
 #include "ob_skinny.h"
-#include "ob_skinny2.h"
 #include "ob_skinny3.h"
 #include "ob_batch.h"
 #include "ob_train.h"
@@ -293,9 +292,6 @@ static void ob_launch_ln_f16(const float *z, const _Float16 *uin, const _Float16
 }
 
 struct ObGemvArgs;
-struct ObSk2Args;
-static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool dry);
-static bool ob_skinny2_shape_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K);
 struct ObSk3Args;
 template <bool PARTIAL> static bool ob_launch_skinny3(const ObSk3Args &a, int grid, int rnt, hipStream_t s);
 static bool ob_skinny3_shape_ok(const void *packed, int64_t ldw_bytes, const void *a, int64_t lda, int64_t T, int64_t K, int64_t N);
@@ -391,30 +387,19 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             rc = ob_single_token_gemv(packed, ldw_bytes, x, h, g, ubuf, K, N, s);
             if (rc) return rc;
         } else if (prescaled && !ob_gemm3_ok(T, K, N)) {
-            // 2 <= T <= 64 on producer-scaled rows: the LDS-DMA skinny GEMM (ob_skinny3.h); OB_SKINNY3=0: the second form
-            // (ob_skinny2.h) where it has an instance
-            static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
-            if (sk3_env && ob_skinny3_shape_ok(packed, ldw_bytes, x, K, T, K, N)) {
-                const int rnt = ob_skinny3_rnt(N);
-                ObSk3Args a = {};
-                a.lda = K; a.T = (int)T;
-                a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, nullptr,
-                          (int)N, (int)K, (int)((N + 16 * rnt - 1) / (16 * rnt))};
-                a.p[1] = a.p[0]; a.p[2] = a.p[0];
-                if (!ob_launch_skinny3<false>(a, a.p[0].wg_end, rnt, s))
-                    return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
-                rc = ob_launch_status("linear_forward(skinny3)");
-                if (rc) return rc;
-            } else {
-                ObSk2Args a = {};
-                a.lda = K; a.T = (int)T; a.K = (int)K;
-                a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, (int)N};
-                a.p[1] = a.p[0]; a.p[2] = a.p[0];
-                if (!ob_skinny2_shape_ok(packed, ldw_bytes, T, K) || !ob_launch_skinny2(a, 1, s, false))
-                    return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
-                rc = ob_launch_status("linear_forward(skinny2)");
-                if (rc) return rc;
-            }
+            // 2 <= T <= 64 on producer-scaled rows: the LDS-DMA skinny GEMM (ob_skinny3.h)
+            if (!ob_skinny3_shape_ok(packed, ldw_bytes, x, K, T, K, N))
+                return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
+            const int rnt = ob_skinny3_rnt(N);
+            ObSk3Args a = {};
+            a.lda = K; a.T = (int)T;
+            a.p[0] = {(const uint32_t *)packed, (long long)(ldw_bytes / 4), (const _Float16 *)g, (const _Float16 *)x, ubuf, nullptr, nullptr,
+                      (int)N, (int)K, (int)((N + 16 * rnt - 1) / (16 * rnt))};
+            a.p[1] = a.p[0]; a.p[2] = a.p[0];
+            if (!ob_launch_skinny3<false>(a, a.p[0].wg_end, rnt, s))
+                return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_PRESCALED on a call no pre-scaled kernel takes");
+            rc = ob_launch_status("linear_forward(skinny3)");
+            if (rc) return rc;
         } else if (prescaled || (ob_gemm3_ok(T, K, N) && workspace && workspace_bytes >= (size_t)T * (size_t)K * 2 && ob_aligned(workspace, 16) &&
                                  ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && N * ldw_bytes < ((int64_t)1 << 32))) {
             // pre-scale once (the fp16 rounding of bitnet.py:113) -- unless the producer of x already did
@@ -775,16 +760,8 @@ extern "C" int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int d
 {
     if (dtype != ONEBIT_F16 || T <= 0 || K <= 0 || N <= 0 || K % 32 != 0) return 0;
     if (ob_gemm3_ok(T, K, N)) return 1;
-    // 2 <= T <= 64: the LDS-DMA skinny GEMM (ob_skinny3.h) consumes pre-scaled rows too (OB_SKINNY3=0: the second form,
-    // ob_skinny2.h, where it has an instance)
-    static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
-    if (sk3_env && T >= 2 && T <= 64 && K % 128 == 0 && K >= 512 && T * K * 2 < ((int64_t)1 << 32)) return 1;
-    if (T >= 2 && T <= 32 && K % 128 == 0 && K >= 512 && K <= 16384) {
-        ObSk2Args a = {};
-        a.T = (int)T; a.K = (int)K; a.p[0].N = a.p[1].N = a.p[2].N = (int)N;
-        return ob_launch_skinny2(a, 1, nullptr, true) ? 1 : 0;
-    }
-    return 0;
+    // 2 <= T <= 64: the LDS-DMA skinny GEMM (ob_skinny3.h) consumes pre-scaled rows too
+    return (T >= 2 && T <= 64 && K % 128 == 0 && K >= 512 && T * K * 2 < ((int64_t)1 << 32)) ? 1 : 0;
 }
 
 extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
@@ -858,49 +835,6 @@ extern "C" size_t onebit_attn_scratch_bytes(const onebit_model_t *m, int32_t S)
 {
     if (!m || S < 2 || m->n_heads <= 0 || m->max_len <= 0) return 0;
     return (size_t)m->n_heads * ((size_t)m->max_len * 4 + (size_t)S * 2 * 4 + (size_t)S * 128 * 4 + 4) + 64;
-}
-
-// ---- skinny GEMM, second form (ob_skinny2.h): pre-scaled rows, 2 <= T <= 32.  Instantiated where it measured faster than
-// the first form: ONE projection with ONE 512-weight chunk per wave (K <= 4096), up to 3 tile slots per workgroup; anything
-// else returns false and the caller takes the first form.
-template <int TT, int MS, int NPROJ, int KV>
-static void ob_launch_sk2_t(const ObSk2Args &a, int G, hipStream_t s)
-{
-    // staging images (8 waves x 16 TT rows x 512 B) reused as the reduction buffer (8 waves x MT x TT KB)
-    const size_t lds = std::max((size_t)OB_DEC_WAVES * MS * NPROJ * TT * 64 * 16, (size_t)OB_DEC_WAVES * 16 * TT * 512);
-    static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_skinny2_kernel<TT, MS, NPROJ, KV>, attr_set, (int)lds);
-    hipLaunchKernelGGL((ob_skinny2_kernel<TT, MS, NPROJ, KV>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
-}
-static bool ob_skinny2_shape_ok(const void *packed, int64_t ldw_bytes, int64_t T, int64_t K)
-{
-    return T >= 2 && T <= 32 && K % 128 == 0 && K >= 512 && K <= 16384 && ldw_bytes % 16 == 0 && ob_aligned(packed, 16);
-}
-static bool ob_skinny2_ok(const onebit_proj_t &p, int64_t T, int64_t K)
-{
-    static const int env = getenv("OB_SKINNY2") ? atoi(getenv("OB_SKINNY2")) : 1;
-    return env && ob_skinny2_shape_ok(p.weight, p.ldw_bytes, T, K);
-}
-static bool ob_launch_skinny2(const ObSk2Args &a, int nproj, hipStream_t s, bool dry)
-{
-    int max_tiles = 0;
-    for (int p = 0; p < nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
-    int G = ob_cu_count();
-    if (max_tiles < G) G = max_tiles;
-    const int MS = (max_tiles + G - 1) / G;
-    const int KV = (((a.K + 511) >> 9) + OB_DEC_WAVES - 1) / OB_DEC_WAVES;
-    const int TT = a.T <= 16 ? 1 : 2;
-    bool hit = false;
-#define OB_SK2(NP_, MS_, KV_)                                                             \
-    if (!hit && nproj == NP_ && MS == MS_ && KV == KV_) {                                 \
-        hit = true;                                                                       \
-        if (dry) { }                                                                      \
-        else if (TT == 1) ob_launch_sk2_t<1, MS_, NP_, KV_>(a, G, s);                     \
-        else ob_launch_sk2_t<2, MS_, NP_, KV_>(a, G, s);                                  \
-    }
-    OB_SK2(1, 1, 1) OB_SK2(1, 2, 1) OB_SK2(1, 3, 1)          // one projection, one chunk per wave (K <= 4096), N up to 48 x CUs rows
-#undef OB_SK2
-    return hit;
 }
 
 // ---- skinny GEMM, LDS-DMA form (ob_skinny3.h): pre-scaled rows, 2 <= T <= 64, 16 * rnt rows per 4-wave workgroup
@@ -1031,8 +965,8 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         }
         // (64 rows per workgroup.  Other tile counts were measured, 32 slots: 128 rows for the wide launches 2.85 vs 2.75 ms
         //  (round 2); 48 rows for q|k|v / 96 for gate|up -- grids of 258 / 230 workgroups for 256 CUs -- 15.5 / 14.1 us against
-        //  14.7 / 14.7 at 7B and slower at 13B (round 3): what bounds these launches is the [T, K] activation block every
-        //  workgroup pulls out of L2, not the grid fit)
+        //  14.7 / 14.7 at 7B and slower at 13B (round 3): the launch is bound by its per-phase instruction stream and barriers,
+        //  not by the grid fit)
         const int rows = 64;
         ObSkinnyArgs ka = {};
         int tiles = 0;
@@ -1076,20 +1010,6 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         splitk_o = m->layers[l].o.weight && m->layers[l].o.ldw_bytes % 16 == 0 &&
                    ob_skinny_ok((const uint32_t *)m->layers[l].o.weight + (H / 2) / 32, m->layers[l].o.ldw_bytes, B, H / 2) &&
                    ob_skinny_ok(m->layers[l].o.weight, m->layers[l].o.ldw_bytes, B, H / 2);
-    // o_proj through the second-form skinny GEMM (ob_skinny2.h) where it applies (2 <= B <= 32, hidden <= 4096: one
-    // 512-weight chunk per wave): the attention kernel then writes its rows times o_proj's input_factor.  Measured at
-    // 7B, 32 slots: 7.9 us against 10.6 us for the split-K first form; the same kernel on the launches with several
-    // projections or several chunks per wave re-reads one [B, K] activation block per projection and chunk out of L2 in
-    // every workgroup and measured slower (q|k|v 22.4, gate|up 18.1, down 16.7 us against 14.8 / 14.8 / 10.6): not used there
-    bool o_sk2 = B <= 32 && NQ == H;
-    for (int l = 0; o_sk2 && l < m->n_layers; ++l) {
-        const onebit_proj_t &po = m->layers[l].o;
-        ObSk2Args ka = {};
-        ka.T = B; ka.K = NQ; ka.p[0].N = ka.p[1].N = ka.p[2].N = H;
-        o_sk2 = po.weight && po.input_factor && po.weight_scale && po.K == NQ && po.N == H && ob_skinny2_ok(po, B, NQ) &&
-                ob_launch_skinny2(ka, 1, s, true);
-    }
-    if (o_sk2) splitk_o = false;
     // Every projection through the LDS-DMA skinny GEMM (ob_skinny3.h) when the state has room for the consumers' pre-scaled
     // rows (x_scaled: 3 x [B, hidden]): the row kernels write fp16(x * h_p) per consuming projection (the rounding of
     // bitnet.py:113 done by the producer), attention and SwiGLU scale their outputs for o_proj / down_proj, down_proj runs
@@ -1170,26 +1090,16 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
-        static const int sk3_o = getenv("OB_SK3_O") ? atoi(getenv("OB_SK3_O")) : 1;          // A/B: o_proj through ob_skinny3 (1) or ob_skinny2 (0)
-        const bool o_sk3 = sk3 && (sk3_o || !o_sk2);
-        if (o_sk2 || o_sk3) at.h_next = (const _Float16 *)L.o.input_factor;
+        if (sk3) at.h_next = (const _Float16 *)L.o.input_factor;
         if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if (o_sk3) {
+        if (sk3) {
             if ((rc = gemm_sk3({&L.o, nullptr, nullptr}, {st->u_o, nullptr, nullptr}, {{nullptr, nullptr, nullptr}},
                                {(const _Float16 *)st->attn_out, nullptr, nullptr}, 1, NQ, "o"))) return rc;
-        } else if (o_sk2) {
-            ObSk2Args ka = {};
-            ka.lda = NQ; ka.T = B; ka.K = NQ;
-            ka.p[0] = {(const uint32_t *)L.o.weight, (long long)(L.o.ldw_bytes / 4), (const _Float16 *)L.o.weight_scale,
-                       (const _Float16 *)st->attn_out, (_Float16 *)st->u_o, nullptr, H};
-            ka.p[1] = ka.p[0]; ka.p[2] = ka.p[0];
-            (void)ob_launch_skinny2(ka, 1, s, false);
-            if ((rc = ob_launch_status("decode_step_batched(o)"))) return rc;
         }
         else if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
         else if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
@@ -1197,7 +1107,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ObBNormArgs nb = na;
         nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
-        if (splitk_o && !o_sk3) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
+        if (splitk_o && !sk3) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
         nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
         if (sk3) {
             nb.x = nullptr; nb.n_scaled = 2; nb.h_next[2] = nullptr; nb.x_scaled[2] = nullptr;

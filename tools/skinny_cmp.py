@@ -1,5 +1,5 @@
 """Per-launch time of the skinny 1-bit GEMM forms (ob_skinny.h on x with the scaling fused; the pre-scaled route on
-producer-scaled rows: ob_skinny3.h, or ob_skinny2.h with OB_SKINNY3=0) at the LLaMA-7B projection shapes, T tokens, one projection per launch, graph-replayed chains
+producer-scaled rows: ob_skinny3.h) at the LLaMA-7B projection shapes, T tokens, one projection per launch, graph-replayed chains
 over 32 distinct weight sets (like bench.py's roofline chains).  Usage: python tools/skinny_cmp.py [T]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
