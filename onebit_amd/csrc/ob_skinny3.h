@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * NW) void ob_skinny3_kernel(const ObSk3Args A)
 #ifndef OB_SK3_ROT
 #define OB_SK3_ROT 1
 #endif
-    const int rot = OB_SK3_ROT ? (int)(blockIdx.x >> 3) % np : 0;
+    int rot = OB_SK3_ROT ? (int)(blockIdx.x >> 3) & 31 : 0;
+    while (rot >= np) rot -= np;                // (np >= 4: a few scalar iterations at most; no integer division in the prologue)
     // (one wait per piece.  Measured and dropped: a separate wait per sub-tile with the transfers in use order -- packed rows
     //  first: every transfer queues behind their HBM fetch, 32-slot step 2.42 vs 2.36 ms; sub-tile 0, rows, sub-tile 1: 2.39)
     auto issue = [&](int i, int buf) {

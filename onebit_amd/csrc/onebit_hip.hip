@@ -1015,8 +1015,10 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     // bitnet.py:113 done by the producer), attention and SwiGLU scale their outputs for o_proj / down_proj, down_proj runs
     // as two K-slices whose fp32 partial sums the next norm kernel adds.  OB_SKINNY3=0: the first-form kernels above.
     static const int sk3_env = getenv("OB_SKINNY3") ? atoi(getenv("OB_SKINNY3")) : 1;
-    _Float16 *xs[3] = {(_Float16 *)st->x_scaled, (_Float16 *)st->x_scaled + (size_t)B * H, (_Float16 *)st->x_scaled + (size_t)2 * B * H};
+    _Float16 *xs[3] = {nullptr, nullptr, nullptr};
     bool sk3 = sk3_env && st->x_scaled && ob_aligned(st->x_scaled, 16) && NQ == H && H % 128 == 0 && I % 256 == 0 && (int64_t)I * 2 >= (int64_t)H * 4;
+    if (sk3)
+        for (int i = 0; i < 3; ++i) xs[i] = (_Float16 *)st->x_scaled + (size_t)i * B * H;
     for (int l = 0; sk3 && l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         const onebit_proj_t *pp[7] = {&L.q, &L.k, &L.v, &L.o, &L.gate, &L.up, &L.down};
