@@ -1048,6 +1048,27 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         if (!ob_launch_skinny3<false>(ka, wgs, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
         return ob_launch_status("decode_step_batched(gemm)");
     };
+    // a projection onto the hidden width (o, down: few rows, so few workgroups) as two K-slices with fp32 partial sums in
+    // zs0 / zs1, added by the next norm kernel: half the activation bytes per workgroup at the same grid (o_proj: 2.24 ->
+    // 2.19-2.21 ms per 32-slot step).  FOUR slices (64-row workgroups, one or two pieces per wave: all ramp and a larger
+    // reduction) measured slower: 2.23 ms at 7B, 3.56 vs 3.46 ms at 13B.
+    auto gemm_sk3_split2 = [&](const onebit_proj_t &p, const _Float16 *a, int64_t K, const char *name) -> int {
+        const int Kh = (int)(K / 2);
+        const int64_t nh[1] = {p.N};
+        const int rnt = ob_skinny3_pick_rnt(nh, 1, 2);
+        const int wg1 = (int)((p.N + 16 * rnt - 1) / (16 * rnt));
+        ObSk3Args ka = {};
+        for (int i = 0; i < 3; ++i) {
+            const int j = i < 2 ? i : 1;
+            ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4), nullptr, a + j * Kh, nullptr,
+                       j == 0 ? zs0 : zs1, nullptr, (int)p.N, Kh, wg1 * (j + 1)};
+        }
+        ka.lda = K; ka.T = B;
+        if (!ob_launch_skinny3<true>(ka, 2 * wg1, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
+        return ob_launch_status("decode_step_batched(split-K gemm)");
+    };
+    static const int sk3_osplit = getenv("OB_SK3_OSPLIT") ? atoi(getenv("OB_SK3_OSPLIT")) : 1;     // A/B: o_proj as two K-slices
+    const bool o_split = sk3 && sk3_osplit && NQ % 256 == 0 && NQ >= 1024;
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -1099,7 +1120,9 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if (sk3) {
+        if (o_split) {
+            if ((rc = gemm_sk3_split2(L.o, (const _Float16 *)st->attn_out, NQ, "o"))) return rc;
+        } else if (sk3) {
             if ((rc = gemm_sk3({&L.o, nullptr, nullptr}, {st->u_o, nullptr, nullptr}, {{nullptr, nullptr, nullptr}},
                                {(const _Float16 *)st->attn_out, nullptr, nullptr}, 1, NQ, "o"))) return rc;
         }
@@ -1109,7 +1132,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ObBNormArgs nb = na;
         nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
-        if (splitk_o && !sk3) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
+        if ((splitk_o && !sk3) || o_split) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
         nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
         if (sk3) {
             nb.x = nullptr; nb.n_scaled = 2; nb.h_next[2] = nullptr; nb.x_scaled[2] = nullptr;
@@ -1130,19 +1153,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
         if (sk3) {
             // two K-slices of the pre-scaled SwiGLU rows, fp32 partial sums (u_gate / u_up are free: SwiGLU has consumed them)
-            const int Kh = I / 2;
-            const int64_t nh[1] = {H};
-            const int rnt = ob_skinny3_pick_rnt(nh, 1, 2);
-            const int wg1 = (H + 16 * rnt - 1) / (16 * rnt);
-            ObSk3Args ka = {};
-            for (int i = 0; i < 3; ++i) {
-                const int j = i < 2 ? i : 1;
-                ka.p[i] = {(const uint32_t *)L.down.weight + j * (Kh / 32), (long long)(L.down.ldw_bytes / 4), nullptr,
-                           (const _Float16 *)st->act + j * Kh, nullptr, j == 0 ? zs0 : zs1, nullptr, H, Kh, wg1 * (j + 1)};
-            }
-            ka.lda = I; ka.T = B;
-            if (!ob_launch_skinny3<true>(ka, 2 * wg1, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for down");
-            if ((rc = ob_launch_status("decode_step_batched(down)"))) return rc;
+            if ((rc = gemm_sk3_split2(L.down, (const _Float16 *)st->act, I, "down"))) return rc;
         } else if (splitk_down) {
             if ((rc = gemm_splitk2(L.down, st->act, I, zs0, zs1, "down"))) return rc;
         } else if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;
