@@ -589,6 +589,17 @@ def main():
             ksd["model"] = "LLaMA-13B shapes"
         except Exception as e:
             ksd = {"error": "%s: %s" % (type(e).__name__, e)}
+    if serve is not None and "error" not in serve and rank == 0 and args.model == "7b":
+        # BASELINE config 5 names LLaMA2-13B: the same 32-slot steady-state step on a 13B-shaped synthetic checkpoint
+        try:
+            stepper = model = None
+            torch.cuda.empty_cache()
+            m13 = build_synthetic_model(model_config("13b"), seed=4242, device=dev)
+            serve["llama2_13b_shapes"] = measure_continuous_batch(m13, dev)
+            del m13
+            torch.cuda.empty_cache()
+        except Exception as e:
+            serve["llama2_13b_shapes"] = {"error": "%s: %s" % (type(e).__name__, e)}
     cpu = None
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -26,7 +26,7 @@ for (T, K, N) in ((32, 4096, 4096), (32, 4096, 12288), (32, 4096, 22016), (32, 1
     a = torch.randn(T, K, generator=g).half().to(dev)
     for m in mods: m.pre_layernorm_prescaled(a)
     torch.cuda.synchronize()
-    acc, raws = [], []
+    acc = []
     for rep in range(6):
         for m in mods[:-1]: m.pre_layernorm_prescaled(a)
         torch.cuda.synchronize()
@@ -37,7 +37,6 @@ for (T, K, N) in ((32, 4096, 4096), (32, 4096, 12288), (32, 4096, 22016), (32, 1
         t[t == 0] = np.nan
         t = t[~np.isnan(t[:, 0, 0])]
         acc.append(t - t[:, :, :1])                # per wave, cycles since its own entry
-        raws = [t]
     s = np.concatenate(acc, axis=0)
     print("T=%d K=%d N=%d (%d workgroups): cycles since the wave's entry   min / median / max over waves" % (T, K, N, len(acc[0])))
     with np.errstate(all="ignore"):
@@ -49,12 +48,6 @@ for (T, K, N) in ((32, 4096, 4096), (32, 4096, 12288), (32, 4096, 22016), (32, 1
         eol = s[:, :, 7]
         inwg = np.nanmax(eol, axis=1) - np.nanmin(eol, axis=1)
         wgend = np.nanmax(s[:, :, 9], axis=1)
-        raw = np.concatenate([b_ for b_ in raws], axis=0)
-        t0 = np.nanmin(raw[:, :, 0])
-        start = np.nanmin(raw[:, :, 0], axis=1) - t0
-        fin = np.nanmax(raw[:, :, 9], axis=1) - t0
     print("    end of K loop, slowest - fastest wave of a workgroup: median %.0f  p90 %.0f   |  workgroup end (since its entry): p10 %.0f median %.0f p90 %.0f max %.0f"
           % (np.nanmedian(inwg), np.nanpercentile(inwg, 90), np.nanpercentile(wgend, 10), np.nanmedian(wgend), np.nanpercentile(wgend, 90), np.nanmax(wgend)))
-    print("    last launch on the chip clock: workgroup entry p10 %.0f median %.0f p90 %.0f max %.0f  |  end median %.0f max %.0f"
-          % (np.nanpercentile(start, 10), np.nanmedian(start), np.nanpercentile(start, 90), np.nanmax(start), np.nanmedian(fin), np.nanmax(fin)))
     del mods
