@@ -4,7 +4,7 @@ O=$R/gpurun_out/r03prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command (CPU baseline skipped: host-side only)
-timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
+timeout 560 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 echo "rc1=$?"; cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv; tail -3 $O/bench_profiled.err
 # 2. FETCH_SIZE pass (own run: counters only beside the kernel trace)
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-prefill --no-serve --no-roofline --no-k-sharded-decode > /dev/null 2> $O/fetch.err
