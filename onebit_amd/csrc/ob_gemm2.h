@@ -351,6 +351,15 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3_f16_kernel(
     // sets): after a barrier all 8 waves would otherwise ask the LDS for 8 KB each at once and the matrix
     // pipe idles until the first answers arrive -- 40 % of the kernel without any staging, by ablation
     ob_half8 bopA[RT], bopB[RT];
+    // s_setprio(1) around the MFMA clusters (two 4-wave workgroups share a CU: the wave that is multiplying keeps the issue
+    // port against the other workgroup's staging / expansion instructions): +1.5 % on all three 7B shapes at T = 16384
+    // (1359 / 1402 / 1258 -> 1380 / 1419 / 1270 TFLOP/s, same box, alternating runs); -DOB_G3_PRIO=0: A/B build.
+    // Measured and dropped: expanding the next row tile's operand into a second register quad between the current
+    // tile's MFMAs (hipcc forms every operand in ONE quad: 8 MFMAs, 8 VALU, hazard nop) -- the kernel sits at 256 VGPRs,
+    // the second quad spills (1321 vs 1370 TFLOP/s).
+#ifndef OB_G3_PRIO
+#define OB_G3_PRIO 1
+#endif
 #ifndef OB_G3_ABL
 #define OB_G3_ABL 0                             // timing experiments only (tools/prefill_probe.py): 1 no operand reads,
 #endif                                          // 2 no sign expansion, 4 no DMA, 8 no wait / barrier -- results are wrong
@@ -395,7 +404,9 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3_f16_kernel(
         asm("" : "+s"(mask));                                                                                            \
         OB_G3_READ(bopB, cur, 1)                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (OB_G3_PRIO) __builtin_amdgcn_s_setprio(1);                                                                   \
         OB_G3_MMA(bopA, 0)                                                                                               \
+        if (OB_G3_PRIO) __builtin_amdgcn_s_setprio(0);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         if (OB_G3_ABL & 8) {                                                                                             \
         } else if (STEADY) {                                                                                             \
@@ -417,7 +428,9 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3_f16_kernel(
         }                                                                                                                \
         if ((STEADY) || kc + 1 < nk) { OB_G3_READ(bopA, (kc + 1) & (OB_G3_BUFS - 1), 0) }                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (OB_G3_PRIO) __builtin_amdgcn_s_setprio(1);                                                                   \
         OB_G3_MMA(bopB, 1)                                                                                               \
+        if (OB_G3_PRIO) __builtin_amdgcn_s_setprio(0);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         if ((Q) & 1) {                                                                                                   \
             /* consume the packed words HERE (32 MFMAs after their ds_read): left pending over the step boundary */     \
