@@ -846,10 +846,7 @@ static void ob_launch_sk3_t(const ObSk3Args &a_in, int grid, hipStream_t s)
     a.dbg = ob_dbg_buffer();
 #endif
     // ring depth per wave: what fits 160 KB of LDS with NW private rings (a piece is 5 / 9 / 17 KB at 16 / 32 / 64 tokens)
-#ifndef OB_SK3_NBUF4
-#define OB_SK3_NBUF4 2
-#endif
-    constexpr int NBUF = RT == 1 ? 3 : (NW == 4 && RT == 2 ? OB_SK3_NBUF4 : 2);
+    constexpr int NBUF = RT == 1 ? 3 : 2;
     constexpr int lds = OB_SK3_LDS(RT, RNT, NBUF, NW);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set[OB_MAX_DEVICES] = {};
@@ -877,17 +874,12 @@ static int ob_skinny3_pick_rnt(const int64_t *N, int np, int copies)
 }
 static int ob_skinny3_rnt(int64_t N) { return ob_skinny3_pick_rnt(&N, 1, 1); }
 // 8 waves (K split eight ways, two waves per SIMD: one wave's transfers wait while the other multiplies) wherever the
-// private rings fit the LDS; 64-token tiles: 4 waves.  OB_SK3_NW=4: A/B switch for the fp16-output instances.
+// private rings fit the LDS; 64-token tiles: 4 waves.  (4-wave workgroups at 16 / 32 tokens were measured and are not built:
+// gate|up 8.9 vs 8.2 us per launch, the K-sliced o / down launches equal.)
 template <bool PARTIAL, int RT, int RNT>
 static void ob_launch_sk3_nw(const ObSk3Args &a, int grid, hipStream_t s)
 {
-    if constexpr (RT == 4) ob_launch_sk3_t<PARTIAL, RT, RNT, 4>(a, grid, s);
-    else if constexpr (PARTIAL) ob_launch_sk3_t<PARTIAL, RT, RNT, 8>(a, grid, s);
-    else {
-        static const int nw_env = getenv("OB_SK3_NW") ? atoi(getenv("OB_SK3_NW")) : 8;
-        if (nw_env == 4) ob_launch_sk3_t<PARTIAL, RT, RNT, 4>(a, grid, s);
-        else ob_launch_sk3_t<PARTIAL, RT, RNT, 8>(a, grid, s);
-    }
+    ob_launch_sk3_t<PARTIAL, RT, RNT, RT == 4 ? 4 : 8>(a, grid, s);
 }
 template <bool PARTIAL>
 static bool ob_launch_skinny3(const ObSk3Args &a, int grid, int rnt, hipStream_t s)
