@@ -145,6 +145,9 @@ int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *
                            int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
 int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next_or_null, void *act, int64_t T,
                        int64_t I, float ln_eps, void *stream);
+/* 1 when a forward call of this shape may pass ONEBIT_FLAG_PRESCALED: fp16 calls that take the LDS-DMA prefill GEMM
+ * (large T) or the LDS-DMA skinny GEMM (2 <= T <= 64, K % 128 == 0, K >= 512); the call itself also needs 16-byte
+ * aligned packed rows / activations.  Every other kernel multiplies by input_factor on the way in and refuses the flag. */
 int onebit_linear_prescaled_ok(int64_t T, int64_t K, int64_t N, int dtype);
 /* The same with the LayerNorm statistics GIVEN (row_stats [T, 4] fp32: {mean, rstd} of the complete gate row, then of
  * the complete up row; 16-byte aligned): for a tensor-parallel rank whose u_gate / u_up hold only its column slice
