@@ -26,6 +26,8 @@ struct ObBNormArgs {
     const _Float16 *h_next[3];
     _Float16 *x_scaled[3];
     int n_scaled;
+    ObPfPlan pf;                  // optional (nseg > 0): packed rows of the next GEMM launch to pull into L2 (ob_common.h) --
+    int pf_rows;                  //   by the workgroups beyond the first pf_rows (= rows) of the grid, which do nothing else
 };
 
 // NV = 8-half vectors per thread actually populated: ceil(H / 4096).  (Sized OB_DEC_MAXV = 4 for every width, a 4096-wide
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
 {
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, H = A.H;
+    if (ob_prefetch_only_wg(A.pf, A.pf_rows, tid, OB_DEC_THREADS)) return;
     const int64_t row = (int64_t)blockIdx.x * H;
     const _Float16 *src = EMBED ? A.embed + (int64_t)A.tokens[blockIdx.x] * H : A.hres_in + row;
     ob_half8 hv[NV], uv[NV];
@@ -127,6 +130,8 @@ struct ObBSwigluArgs {
     const _Float16 *h_next;          // optional: act <- fp16(act * h_next), the consumer's pre-scaled activations
     const float *ext;                // optional [B, 4] {mean, rstd} of the COMPLETE gate and up rows: the rows given here are a
                                      // column slice (tensor-parallel N-shard), their statistics were combined across ranks
+    ObPfPlan pf;                     // optional (nseg > 0): packed rows of the next GEMM launch to pull into L2, by the
+    int pf_rows;                     //   workgroups beyond the first pf_rows (= rows) of the grid
 };
 
 template <int NV>
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
 {
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, I = A.I;
+    if (ob_prefetch_only_wg(A.pf, A.pf_rows, tid, OB_DEC_THREADS)) return;
     const int64_t row = (int64_t)blockIdx.x * I;
     ob_half8 g8[NV], u8[NV], hn[NV];
     bool valid[NV];

@@ -92,3 +92,56 @@ __device__ __forceinline__ void ob_expand16(uint32_t bits16, uint32_t (&out)[8])
 #pragma unroll
     for (int p = 0; p < 8; ++p) out[p] = ((c << (15 - 2 * p)) & mask) | (0x3C003C00u & ~mask);
 }
+
+// ---------------------------------------------------------------------------------------------
+// L2 prefetch of the NEXT launch's packed rows (batched decode step).  The skinny GEMM launches are short (5-14 us) and
+// their first math waits for the first piece of packed rows from HBM (~2 us into the launch: transfers complete in
+// order, so the L2-resident activation rows queue behind it); the row kernels and the attention kernel before them are
+// 32- / 1024-workgroup latency chains with the memory system idle.  So the producer touches one dword of every
+// 128-byte line of the consumer's rows, split so that a workgroup touches the rows of GEMM workgroups ON ITS OWN XCD
+// (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): the GEMM then finds its rows in L2.
+// A wrong guess of the placement costs nothing but the benefit.  Measured with the rows L2-resident: -1.0 us per launch.
+// ---------------------------------------------------------------------------------------------
+struct ObPfSeg {
+    const char *base;             // first row of the segment (a projection, or a K-slice of one)
+    long long ld_bytes;           // row pitch
+    int row_bytes;                // bytes of a row that the consumer reads (K / 8 of the slice)
+    int rows_per_wg, nrows;       // consumer workgroup b of [wg_begin, wg_end) reads rows (b - wg_begin) * rows_per_wg ...
+    int wg_begin, wg_end;
+};
+struct ObPfPlan { ObPfSeg s[4]; int nseg; };
+
+// x = XCD of this workgroup (its linear index in the grid & 7), j / nj = its rank among / the number of the grid's
+// prefetching workgroups on that XCD; returns a value that depends on every loaded dword (keep it alive to the end of the
+// kernel: ob_pf_keep) so that the loads are neither dropped nor waited for early.
+// WHO prefetches matters: a CU keeps ~64 missed lines (8 KB) in flight, i.e. ~20 GB/s against HBM latency -- the 32
+// workgroups of a row kernel would need 10-20 us for a launch's 6-11 MB (measured: the step 2.27 -> 2.75 ms).  The row
+// kernels are therefore launched with one EXTRA workgroup per otherwise idle CU that does nothing else.
+__device__ __forceinline__ uint32_t ob_prefetch_l2(const ObPfPlan &P, int x, int j, int nj, int tid, int nthr)
+{
+    uint32_t acc = 0;
+    for (int si = 0; si < P.nseg; ++si) {
+        const ObPfSeg S = P.s[si];
+        const int lines = (S.row_bytes + 127) >> 7;
+        const int first = S.wg_begin + ((x - S.wg_begin) & 7);          // this XCD's consumers: first, first + 8, ...
+        for (int b = first + 8 * j; b < S.wg_end; b += 8 * nj) {
+            const int r0 = (b - S.wg_begin) * S.rows_per_wg;
+            const int total = min(S.rows_per_wg, S.nrows - r0) * lines;
+            for (int t = tid; t < total; t += nthr) {
+                const int r = t / lines, l = t - r * lines;
+                acc ^= *reinterpret_cast<const uint32_t *>(S.base + (long long)(r0 + r) * S.ld_bytes + min(l * 128, S.row_bytes - 4));
+            }
+        }
+    }
+    return acc;
+}
+// a grid of `nrows` working workgroups followed by prefetch-only ones: true (and done) for the latter
+__device__ __forceinline__ bool ob_prefetch_only_wg(const ObPfPlan &P, int nrows, int tid, int nthr)
+{
+    const int w = (int)blockIdx.x;
+    if (P.nseg <= 0 || w < nrows) return false;
+    const int x = w & 7, first = nrows + ((x - nrows) & 7);
+    const uint32_t acc = ob_prefetch_l2(P, x, (w - first) >> 3, ((int)gridDim.x - first + 7) >> 3, tid, nthr);
+    asm volatile("" :: "v"(acc));
+    return true;
+}

@@ -1023,41 +1023,57 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     }
     const bool down_parts = sk3 || splitk_down;
     struct A3 { const _Float16 *a[3]; };
-    auto gemm_sk3 = [&](P3 ps, U3 us, S3 ss, A3 as, int np, int64_t K, const char *name) -> int {
+    // the launch description of a skinny GEMM is built BEFORE its producer kernel is launched: the producer pulls the
+    // packed rows of exactly these workgroups into the L2 of the XCD they will run on (ob_common.h, ob_prefetch_l2)
+    struct Sk3Launch { ObSk3Args ka; int wgs, rnt, nseg; bool partial; };
+    auto build_sk3 = [&](P3 ps, U3 us, S3 ss, A3 as, int np, int64_t K) -> Sk3Launch {
+        Sk3Launch L3 = {};
         int64_t nn[3] = {0, 0, 0};
         for (int i = 0; i < np; ++i) nn[i] = ps.p[i]->N;
-        const int rnt = ob_skinny3_pick_rnt(nn, np, 1);
-        ObSk3Args ka = {};
-        int wgs = 0;
+        L3.rnt = ob_skinny3_pick_rnt(nn, np, 1);
         for (int i = 0; i < 3; ++i) {
             const int j = i < np ? i : np - 1;
             const onebit_proj_t &p = *ps.p[j];
-            if (i < np) wgs += (int)((p.N + 16 * rnt - 1) / (16 * rnt));
-            ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.weight_scale, as.a[j],
-                       (_Float16 *)us.u[j], nullptr, ss.s[j], (int)p.N, (int)K, wgs};
+            if (i < np) L3.wgs += (int)((p.N + 16 * L3.rnt - 1) / (16 * L3.rnt));
+            L3.ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.weight_scale, as.a[j],
+                          (_Float16 *)us.u[j], nullptr, ss.s[j], (int)p.N, (int)K, L3.wgs};
         }
-        ka.lda = K; ka.T = B;
-        if (!ob_launch_skinny3<false>(ka, wgs, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
-        return ob_launch_status("decode_step_batched(gemm)");
+        L3.ka.lda = K; L3.ka.T = B; L3.nseg = np; L3.partial = false;
+        return L3;
     };
     // a projection onto the hidden width (o, down: few rows, so few workgroups) as two K-slices with fp32 partial sums in
     // zs0 / zs1, added by the next norm kernel: half the activation bytes per workgroup at the same grid (o_proj: 2.24 ->
     // 2.19-2.21 ms per 32-slot step).  FOUR slices (64-row workgroups, one or two pieces per wave: all ramp and a larger
     // reduction) measured slower: 2.23 ms at 7B, 3.56 vs 3.46 ms at 13B.
-    auto gemm_sk3_split2 = [&](const onebit_proj_t &p, const _Float16 *a, int64_t K, const char *name) -> int {
+    auto build_sk3_split2 = [&](const onebit_proj_t &p, const _Float16 *a, int64_t K) -> Sk3Launch {
+        Sk3Launch L3 = {};
         const int Kh = (int)(K / 2);
         const int64_t nh[1] = {p.N};
-        const int rnt = ob_skinny3_pick_rnt(nh, 1, 2);
-        const int wg1 = (int)((p.N + 16 * rnt - 1) / (16 * rnt));
-        ObSk3Args ka = {};
+        L3.rnt = ob_skinny3_pick_rnt(nh, 1, 2);
+        const int wg1 = (int)((p.N + 16 * L3.rnt - 1) / (16 * L3.rnt));
         for (int i = 0; i < 3; ++i) {
             const int j = i < 2 ? i : 1;
-            ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4), nullptr, a + j * Kh, nullptr,
-                       j == 0 ? zs0 : zs1, nullptr, (int)p.N, Kh, wg1 * (j + 1)};
+            L3.ka.p[i] = {(const uint32_t *)p.weight + j * (Kh / 32), (long long)(p.ldw_bytes / 4), nullptr, a + j * Kh, nullptr,
+                          j == 0 ? zs0 : zs1, nullptr, (int)p.N, Kh, wg1 * (j + 1)};
         }
-        ka.lda = K; ka.T = B;
-        if (!ob_launch_skinny3<true>(ka, 2 * wg1, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
-        return ob_launch_status("decode_step_batched(split-K gemm)");
+        L3.ka.lda = K; L3.ka.T = B; L3.wgs = 2 * wg1; L3.nseg = 2; L3.partial = true;
+        return L3;
+    };
+    static const int sk3_pf = getenv("OB_SK3_PREFETCH") ? atoi(getenv("OB_SK3_PREFETCH")) : 1;     // A/B: producers prefetch the consumer's rows
+    auto plan_of = [&](const Sk3Launch &L3) -> ObPfPlan {
+        ObPfPlan P = {};
+        if (!sk3_pf) return P;
+        for (int i = 0; i < L3.nseg; ++i) {
+            const ObSk3Proj &q = L3.ka.p[i];
+            P.s[i] = {(const char *)q.W, q.ldw_words * 4, q.K / 8, 16 * L3.rnt, q.N, i ? L3.ka.p[i - 1].wg_end : 0, q.wg_end};
+        }
+        P.nseg = L3.nseg;
+        return P;
+    };
+    auto launch_sk3 = [&](const Sk3Launch &L3, const char *name) -> int {
+        const bool ok = L3.partial ? ob_launch_skinny3<true>(L3.ka, L3.wgs, L3.rnt, s) : ob_launch_skinny3<false>(L3.ka, L3.wgs, L3.rnt, s);
+        if (!ok) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: no skinny GEMM instance for %s", name);
+        return ob_launch_status("decode_step_batched(gemm)");
     };
     static const int sk3_osplit = getenv("OB_SK3_OSPLIT") ? atoi(getenv("OB_SK3_OSPLIT")) : 1;     // A/B: o_proj as two K-slices
     const bool o_split = sk3 && sk3_osplit && NQ % 256 == 0 && NQ >= 1024;
@@ -1065,6 +1081,20 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
             return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer in layer %d", l);
+        S3 qs = {{nullptr, nullptr, nullptr}};
+        if (st->qkv_stats && NQ % 16 == 0 && NK % 16 == 0) {
+            const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
+            qs.s[0] = st->qkv_stats; qs.s[1] = st->qkv_stats + (size_t)B * fq; qs.s[2] = st->qkv_stats + (size_t)B * (fq + fk);
+        }
+        Sk3Launch g_qkv = {}, g_o = {}, g_gu = {}, g_down = {};
+        if (sk3) {
+            const S3 none = {{nullptr, nullptr, nullptr}};
+            g_qkv = build_sk3({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, qs, {xs[0], xs[1], xs[2]}, 3, H);
+            g_o = o_split ? build_sk3_split2(L.o, (const _Float16 *)st->attn_out, NQ)
+                          : build_sk3({&L.o, nullptr, nullptr}, {st->u_o, nullptr, nullptr}, none, {(const _Float16 *)st->attn_out, nullptr, nullptr}, 1, NQ);
+            g_gu = build_sk3({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, none, {xs[0], xs[1], nullptr}, 2, H);
+            g_down = build_sk3_split2(L.down, (const _Float16 *)st->act, I);
+        }
         // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm
         ObBNormArgs na = {};
         na.embed = (const _Float16 *)m->embed; na.tokens = st->tokens; na.hres_in = hA;
@@ -1076,20 +1106,17 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             na.x = nullptr; na.n_scaled = 3;
             na.h_next[0] = (const _Float16 *)L.q.input_factor; na.h_next[1] = (const _Float16 *)L.k.input_factor; na.h_next[2] = (const _Float16 *)L.v.input_factor;
             na.x_scaled[0] = xs[0]; na.x_scaled[1] = xs[1]; na.x_scaled[2] = xs[2];
+            na.pf = plan_of(g_qkv); na.pf_rows = B;
         }
-        if (l == 0) OB_LAUNCH_NORM(true, H, dim3(B), s, na);
-        else OB_LAUNCH_NORM(false, H, dim3(B), s, na);
+        const int pf_grid = (sk3 && sk3_pf) ? std::max(B, ob_cu_count()) : B;      // rows + one prefetch-only workgroup per idle CU
+        if (l == 0) OB_LAUNCH_NORM(true, H, dim3(pf_grid), s, na);
+        else OB_LAUNCH_NORM(false, H, dim3(pf_grid), s, na);
         if ((rc = ob_launch_status("decode_step_batched(norm)"))) return rc;
         // 2. q, k, v: one launch when the skinny kernel takes all three
         //    (its epilogue also publishes the LayerNorm partials of the three rows per slot, so the (head, slot)
         //    attention workgroups do not each re-reduce the whole q / k / v rows)
-        S3 qs = {{nullptr, nullptr, nullptr}};
-        if (st->qkv_stats && NQ % 16 == 0 && NK % 16 == 0) {
-            const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
-            qs.s[0] = st->qkv_stats; qs.s[1] = st->qkv_stats + (size_t)B * fq; qs.s[2] = st->qkv_stats + (size_t)B * (fq + fk);
-        }
         if (sk3) {
-            if ((rc = gemm_sk3({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, qs, {xs[0], xs[1], xs[2]}, 3, H, "qkv"))) return rc;
+            if ((rc = launch_sk3(g_qkv, "qkv"))) return rc;
             stats_written = qs.s[0] != nullptr;
         } else if ((rc = gemm_multi({&L.q, &L.k, &L.v}, {st->u_q, st->u_k, st->u_v}, {NQ, NK, NK}, qs, 3, st->x, H, "qkv"))) return rc;
         const bool attn_pst = stats_written;
@@ -1105,6 +1132,8 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
+        // (the attention workgroups do not prefetch o_proj's rows: measured, the (head, slot) chains got 3.3 us longer for
+        //  0.5 us off the o_proj launch)
         if (sk3) at.h_next = (const _Float16 *)L.o.input_factor;
         if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
@@ -1112,17 +1141,12 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
-        if (o_split) {
-            if ((rc = gemm_sk3_split2(L.o, (const _Float16 *)st->attn_out, NQ, "o"))) return rc;
-        } else if (sk3) {
-            if ((rc = gemm_sk3({&L.o, nullptr, nullptr}, {st->u_o, nullptr, nullptr}, {{nullptr, nullptr, nullptr}},
-                               {(const _Float16 *)st->attn_out, nullptr, nullptr}, 1, NQ, "o"))) return rc;
-        }
+        if (sk3) { if ((rc = launch_sk3(g_o, "o"))) return rc; }
         else if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
         else if ((rc = gemm(L.o, st->attn_out, st->u_o, NQ, H, "o"))) return rc;
         // 5. residual + LayerNorm(u_o) + post-attention RMSNorm
         ObBNormArgs nb = na;
-        nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr;
+        nb.z0 = nb.z1 = nullptr; nb.g_prev = nullptr; nb.pf = {};
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
         if ((splitk_o && !sk3) || o_split) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
         nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
@@ -1130,22 +1154,24 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             nb.x = nullptr; nb.n_scaled = 2; nb.h_next[2] = nullptr; nb.x_scaled[2] = nullptr;
             nb.h_next[0] = (const _Float16 *)L.gate.input_factor; nb.h_next[1] = (const _Float16 *)L.up.input_factor;
             nb.x_scaled[0] = xs[0]; nb.x_scaled[1] = xs[1];
+            nb.pf = plan_of(g_gu); nb.pf_rows = B;
         }
-        OB_LAUNCH_NORM(false, H, dim3(B), s, nb);
+        OB_LAUNCH_NORM(false, H, dim3(pf_grid), s, nb);
         if ((rc = ob_launch_status("decode_step_batched(norm2)"))) return rc;
         // 6. gate, up; 7. SiLU(LN(gate)) * LN(up); 8. down
         if (sk3) {
-            if ((rc = gemm_sk3({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {{nullptr, nullptr, nullptr}}, {xs[0], xs[1], nullptr}, 2, H, "gate|up"))) return rc;
+            if ((rc = launch_sk3(g_gu, "gate|up"))) return rc;
         } else if ((rc = gemm_multi({&L.gate, &L.up, nullptr}, {st->u_gate, st->u_up, nullptr}, {I, I, 0}, {{nullptr, nullptr, nullptr}}, 2, st->x, H, "gate|up"))) return rc;
         ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps,
                             sk3 ? (const _Float16 *)L.down.input_factor : nullptr, nullptr};
-        OB_LAUNCH_SWIGLU(I, dim3(B), s, sa);
+        if (sk3) { sa.pf = plan_of(g_down); sa.pf_rows = B; }
+        OB_LAUNCH_SWIGLU(I, dim3(pf_grid), s, sa);
         if ((rc = ob_launch_status("decode_step_batched(swiglu)"))) return rc;
         // 8. down: short and wide (N = hidden, K = intermediate) -- split K over two workgroup ranges
         //    (fp32 partial sums into the free u_gate / u_up buffers), summed by the next norm kernel
         if (sk3) {
             // two K-slices of the pre-scaled SwiGLU rows, fp32 partial sums (u_gate / u_up are free: SwiGLU has consumed them)
-            if ((rc = gemm_sk3_split2(L.down, (const _Float16 *)st->act, I, "down"))) return rc;
+            if ((rc = launch_sk3(g_down, "down"))) return rc;
         } else if (splitk_down) {
             if ((rc = gemm_splitk2(L.down, st->act, I, zs0, zs1, "down"))) return rc;
         } else if ((rc = gemm(L.down, st->act, st->u_down, I, H, "down"))) return rc;

@@ -28,6 +28,7 @@ def chain_us(fn, mods):
     return e0.elapsed_time(e1) * 1e3 / (10 * len(mods))
 for name, K, N in (("q/o 4096->4096", 4096, 4096), ("gate 4096->11008", 4096, 11008), ("down 11008->4096", 11008, 4096)):
     mods = [mk(K, N) for _ in range(24)]
+    if os.environ.get("REUSE"): mods = [mods[0]] * 24        # the same packed matrix every launch: its rows stay in the XCDs' L2
     x = torch.randn(T, K, generator=g).half().to(dev)
     a = x * mods[0].input_factor.data
     ok = mods[0].prescaled_ok(T)
