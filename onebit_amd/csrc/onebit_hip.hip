@@ -1133,7 +1133,8 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
         // (the attention workgroups do not prefetch o_proj's rows: measured, the (head, slot) chains got 3.3 us longer for
-        //  0.5 us off the o_proj launch)
+        //  0.5 us off the o_proj launch; nor do the 64 CUs the q|k|v launch leaves idle: the attention launch's K / V
+        //  stream runs through the same L2 in between, 2.18 vs 2.19 ms)
         if (sk3) at.h_next = (const _Float16 *)L.o.input_factor;
         if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
