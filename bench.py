@@ -148,6 +148,8 @@ def measure_roofline(model, dev, ms_per_token, tok_bytes):
     st = {k: torch.zeros(tile_stats_floats(n), device=dev) for k, n in dict(h=H, q=H, k=H, v=H, o=H, g=I, u=I, d=H, gi=I, ui=I).items()}
     layers = list(model.model.layers)
     L = len(layers)
+    if os.environ.get("OB_BENCH_REUSE_WEIGHTS"):        # diagnostic: every launch of a chain on ONE layer's matrices (L2-resident rows)
+        layers = [layers[0]] * L
     ab = algorithmic_bytes
     kinds = {
         "qkv": (lambda l: fused_gemv([l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj], [o["q"], o["k"], o["v"]],

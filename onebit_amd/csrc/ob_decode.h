@@ -304,7 +304,11 @@ __device__ __forceinline__ ob_u32x4 ob_dec_load_w(const uint32_t *w, int N, int 
     ob_u32x4 w4;
     if (ALIGNED) {
         const int wc = min(word, nwords - 4);
-        w4 = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(rowp + wc));
+#ifndef OB_DEC_W_NT
+#define OB_DEC_W_NT 1                           // 0: allocating loads (A/B build for the L2-residency experiment)
+#endif
+        if (OB_DEC_W_NT) w4 = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(rowp + wc));
+        else w4 = *reinterpret_cast<const ob_u32x4 *>(rowp + wc);
         if (word >= nwords) w4 = (ob_u32x4){0u, 0u, 0u, 0u};
     } else {
 #pragma unroll
