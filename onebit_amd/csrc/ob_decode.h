@@ -1032,9 +1032,13 @@ __device__ __forceinline__ float ob_rows_max(float v)
 // BLIND: fetch the first 128 cached positions before the position is known (single sequence: 32 workgroups,
 // latency is everything).  The batched step runs heads x slots workgroups -- 64 KB of blind cache reads each
 // were 64 MB per layer at 32 slots, 13 of the kernel's 16 us -- and reads the position first.
+// PF (single sequence only): the launch runs one workgroup per head on a 256-CU chip -- the grid carries one extra
+// workgroup per idle CU that does nothing but pull o_proj's packed rows (the next launch: 2 MB) into the L2 of the XCD
+// whose workgroups will read them (ob_common.h).
 template <bool PST, int NTH, bool BLIND = true>
-__global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in)
+__global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in, const ObPfPlan PF)
 {
+    if (BLIND && ob_prefetch_only_wg(PF, A_in.H, (int)threadIdx.x, NTH)) return;
     constexpr int NWV = NTH / 64, PG = NTH / 16, NI = 128 / PG;
     ObAttnArgs A = A_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -642,6 +642,46 @@ extern "C" int onebit_debug_read_timing(unsigned long long *host_out, int nblock
 }
 #endif
 
+// grid and tile slots of a decode GEMV launch: workgroup b of G owns tiles b, b + G, ... (MS slots) of every projection
+static void ob_dec_gemv_geometry(const ObGemvArgs &a, int &max_tiles, int &KV, bool &aligned, int &G, int &MS)
+{
+    max_tiles = 0;
+    for (int p = 0; p < a.nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
+    const int Kpad = (a.K + 511) & ~511;
+    const int nchunks = Kpad / 512;
+    const int kv_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;       // = ceil(K / 4096)
+    KV = kv_need <= 4 ? kv_need : 4;
+    aligned = a.K % 128 == 0;
+    for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
+    // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
+    // one workgroup per CU when a projection has more tiles than that
+    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);      // KV 3, 4: one slot
+    static const int wgs_per_cu = getenv("OB_DEC_WGS_PER_CU") ? atoi(getenv("OB_DEC_WGS_PER_CU")) : 1;   // A/B switch
+    G = ob_cu_count() * (wgs_per_cu > 0 ? wgs_per_cu : 1);
+    if (max_tiles < G) G = max_tiles;
+    if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
+    MS = (max_tiles + G - 1) / G;
+}
+
+// The packed rows a decode GEMV launch will read, as a prefetch plan for a launch BEFORE it (ob_common.h): consuming
+// workgroup b reads, per projection and slot s, the 16 rows of tile s * G + b.
+static ObPfPlan ob_dec_gemv_plan(const ObGemvArgs &a)
+{
+    ObPfPlan P = {};
+    int max_tiles, KV, G, MS;
+    bool aligned;
+    ob_dec_gemv_geometry(a, max_tiles, KV, aligned, G, MS);
+    if (!aligned || G <= 0 || G > ob_cu_count()) return P;          // (the XCD of consuming workgroup b is b & 7 only within one round)
+    for (int p = 0; p < a.nproj; ++p)
+        for (int sl = 0; sl < MS && P.nseg < 4; ++sl) {
+            const int r0 = sl * G * 16;
+            if (r0 >= a.p[p].N) break;
+            P.s[P.nseg++] = {(const char *)(a.p[p].w + (size_t)r0 * a.p[p].ldw), (long long)a.p[p].ldw * 4, a.K / 8, 16, a.p[p].N - r0,
+                             0, std::min(G, (a.p[p].N - r0 + 15) / 16)};
+        }
+    return P;
+}
+
 static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 {
     ObGemvArgs a = a_in;
@@ -649,24 +689,12 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 #ifdef OB_PROFILE_STAMPS
     a.dbg = ob_dbg_buffer();
 #endif
-    int max_tiles = 0;
-    for (int p = 0; p < a.nproj; ++p) max_tiles = std::max(max_tiles, (a.p[p].N + 15) / 16);
+    int max_tiles, KV, G, MS;
+    bool aligned;
+    ob_dec_gemv_geometry(a, max_tiles, KV, aligned, G, MS);
     const int Kpad = (a.K + 511) & ~511;
-    const int nchunks = Kpad / 512;
-    const int kv_need = (nchunks + OB_DEC_WAVES - 1) / OB_DEC_WAVES;       // = ceil(K / 4096)
-    const int KV = kv_need <= 4 ? kv_need : 4;
-    bool aligned = a.K % 128 == 0;
-    for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
     if (!aligned && KV != 1)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
-    // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
-    // one workgroup per CU when a projection has more tiles than that
-    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);      // KV 3, 4: one slot
-    static const int wgs_per_cu = getenv("OB_DEC_WGS_PER_CU") ? atoi(getenv("OB_DEC_WGS_PER_CU")) : 1;   // A/B switch
-    int G = ob_cu_count() * (wgs_per_cu > 0 ? wgs_per_cu : 1);
-    if (max_tiles < G) G = max_tiles;
-    if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
-    const int MS = (max_tiles + G - 1) / G;
     const int MT = MS * a.nproj;
     const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
@@ -1136,10 +1164,10 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         //  0.5 us off the o_proj launch; nor do the 64 CUs the q|k|v launch leaves idle: the attention launch's K / V
         //  stream runs through the same L2 in between, 2.18 vs 2.19 ms)
         if (sk3) at.h_next = (const _Float16 *)L.o.input_factor;
-        if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
-        else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
-        else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at);
-        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at);
+        if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
+        else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
+        else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
+        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
         // 4. o_proj
         if (sk3) { if ((rc = launch_sk3(g_o, "o"))) return rc; }
@@ -1290,6 +1318,11 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         a.rms_w = (const _Float16 *)L.input_layernorm_w;
         a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(a, s))) return rc;
+        // K3's launch description first: the attention launch's idle CUs prefetch its packed rows
+        ObGemvArgs o = {};
+        o.nproj = 1; o.K = (int)L.o.K; o.prologue = OB_P_PLAIN; o.xin = (const _Float16 *)st->attn_out;
+        if ((rc = ob_fill_proj(o.p[0], L.o, st->u_o, "o_proj", ts_o))) return rc;
+        o.rms_eps = m->rms_eps; o.ln_eps = m->ln_eps;
         // K2: attention
         ObAttnArgs at = {};
         at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
@@ -1319,16 +1352,19 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
             if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step: max_len %d too large for the attention kernel", m->max_len);
             // one wave per SIMD (256 threads) for the single sequence; OB_ATTN_THREADS=512 restores 8 waves (A/B)
             static const int attn_threads = getenv("OB_ATTN_THREADS") ? atoi(getenv("OB_ATTN_THREADS")) : 256;
-            if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(m->n_heads), dim3(256), attn_lds, s, at);
-            else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512>), dim3(m->n_heads), dim3(512), attn_lds, s, at);
-            else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(m->n_heads), dim3(512), attn_lds, s, at);
+            // o_proj's packed rows (the next launch, 2 MB at 7B) are pulled into L2 by one extra workgroup per CU the heads
+            // leave idle: 986-989 -> 1004 tok/s on one box, alternating runs.  (The same for gate|up's 11 MB, or from the
+            // GEMV launches' tails, loses: DESIGN.md section 6.)
+            static const int attn_pf_env = getenv("OB_DEC_PREFETCH_O") ? atoi(getenv("OB_DEC_PREFETCH_O")) : 1;
+            ObPfPlan apf = {};
+            if (attn_pf_env && m->n_heads < ob_cu_count()) apf = ob_dec_gemv_plan(o);
+            const int agrid = apf.nseg ? ob_cu_count() : m->n_heads;
+            if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
+            else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
+            else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
             if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
         }
         // K3: o_proj
-        ObGemvArgs o = {};
-        o.nproj = 1; o.K = (int)L.o.K; o.prologue = OB_P_PLAIN; o.xin = (const _Float16 *)st->attn_out;
-        if ((rc = ob_fill_proj(o.p[0], L.o, st->u_o, "o_proj", ts_o))) return rc;
-        o.rms_eps = m->rms_eps; o.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(o, s))) return rc;
         // K4: residual + LN(u_o) -> RMSNorm -> gate, up
         ObGemvArgs gu = {};
