@@ -94,13 +94,14 @@ __device__ __forceinline__ void ob_expand16(uint32_t bits16, uint32_t (&out)[8])
 }
 
 // ---------------------------------------------------------------------------------------------
-// L2 prefetch of the NEXT launch's packed rows (batched decode step).  The skinny GEMM launches are short (5-14 us) and
-// their first math waits for the first piece of packed rows from HBM (~2 us into the launch: transfers complete in
-// order, so the L2-resident activation rows queue behind it); the row kernels and the attention kernel before them are
-// 32- / 1024-workgroup latency chains with the memory system idle.  So the producer touches one dword of every
-// 128-byte line of the consumer's rows, split so that a workgroup touches the rows of GEMM workgroups ON ITS OWN XCD
-// (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): the GEMM then finds its rows in L2.
-// A wrong guess of the placement costs nothing but the benefit.  Measured with the rows L2-resident: -1.0 us per launch.
+// L2 prefetch of the NEXT launch's packed rows by the CUs a launch leaves idle.  The skinny GEMM launches of the batched
+// step are short (5-14 us) and their first math waits for the first piece of packed rows from HBM (~2 us into the launch:
+// transfers complete in order, so the L2-resident activation rows queue behind it); the row kernels before them run 32
+// workgroups on a 256-CU chip.  Those launches carry one EXTRA workgroup per idle CU that does nothing but touch one dword
+// of every 128-byte line of the consumer's rows -- the rows of the consuming workgroups on ITS OWN XCD (workgroups are dealt
+// round-robin to the 8 XCDs, each with its own L2): the GEMM then finds its rows in L2 (measured with the rows resident:
+// -1.0 us per launch).  A wrong guess of the placement costs nothing but the benefit.  The single-sequence decode step does
+// the same for o_proj's rows from the attention launch (one workgroup per head).
 // ---------------------------------------------------------------------------------------------
 struct ObPfSeg {
     const char *base;             // first row of the segment (a projection, or a K-slice of one)
@@ -112,11 +113,10 @@ struct ObPfSeg {
 struct ObPfPlan { ObPfSeg s[4]; int nseg; };
 
 // x = XCD of this workgroup (its linear index in the grid & 7), j / nj = its rank among / the number of the grid's
-// prefetching workgroups on that XCD; returns a value that depends on every loaded dword (keep it alive to the end of the
-// kernel: ob_pf_keep) so that the loads are neither dropped nor waited for early.
-// WHO prefetches matters: a CU keeps ~64 missed lines (8 KB) in flight, i.e. ~20 GB/s against HBM latency -- the 32
-// workgroups of a row kernel would need 10-20 us for a launch's 6-11 MB (measured: the step 2.27 -> 2.75 ms).  The row
-// kernels are therefore launched with one EXTRA workgroup per otherwise idle CU that does nothing else.
+// prefetching workgroups on that XCD; returns a value that depends on every loaded dword (so the loads are not dropped).
+// WHO prefetches matters: a CU keeps ~64 missed lines (8 KB) in flight, i.e. 8-20 GB/s against HBM latency -- the 32
+// working workgroups of a row kernel would need 10-20 us for a launch's 6-11 MB (measured: the step 2.27 -> 2.75 ms), and
+// a kernel cannot end before its loads have returned (s_endpgm waits): dedicated workgroups on otherwise idle CUs.
 __device__ __forceinline__ uint32_t ob_prefetch_l2(const ObPfPlan &P, int x, int j, int nj, int tid, int nthr)
 {
     uint32_t acc = 0;
