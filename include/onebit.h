@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 6
+#define ONEBIT_ABI_VERSION 7
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -293,6 +293,11 @@ typedef struct onebit_batch_state {
      * of a layer take the LDS-DMA skinny GEMM (same sums, fp32 accumulation order differs).  NULL: the projections
      * scale x themselves.                                                                                          */
     void *x_scaled;
+    /* ABI 7: independent chains.  0 / 1: all B rows in one launch chain.  2..4: the rows as that many groups of consecutive
+     * slots, each group's layers on its own HIP stream forked from / joined to `stream` (parallel branches under graph
+     * capture), one lm_head over all rows.  Per-row results do not depend on the grouping.  The side streams are created
+     * on the first such call, which must not be inside a stream capture.                                            */
+    int32_t chains;
 } onebit_batch_state_t;
 
 size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);

@@ -18,7 +18,7 @@ ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
 FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
 FLAG_PRESCALED = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
 _i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint

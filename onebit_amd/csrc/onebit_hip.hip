@@ -921,26 +921,17 @@ static bool ob_launch_skinny3(const ObSk3Args &a, int grid, int rnt, hipStream_t
     }
     OB_SK3(1, 1) OB_SK3(1, 2) OB_SK3(1, 3) OB_SK3(1, 4) OB_SK3(1, 6) OB_SK3(1, 8)
     OB_SK3(2, 1) OB_SK3(2, 2) OB_SK3(2, 3) OB_SK3(2, 4) OB_SK3(2, 6) OB_SK3(2, 8)
-    OB_SK3(4, 1) OB_SK3(4, 2) OB_SK3(4, 3) OB_SK3(4, 4) OB_SK3(4, 6)
+    OB_SK3(4, 1) OB_SK3(4, 2) OB_SK3(4, 3) OB_SK3(4, 4) OB_SK3(4, 6) OB_SK3(4, 8)
 #undef OB_SK3
     return hit;
 }
 
-extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
+static int ob_batched_head(const onebit_model_t *m, const onebit_batch_state_t *st, hipStream_t s);
+
+// The decoder layers + final norm of the batched step for the `st->batch` sequences whose first KV-cache slot is
+// `slot0` (every pointer of `st` already addresses row 0 of that range; the caches are indexed from the model).
+static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t *st, int slot0, hipStream_t s)
 {
-    if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
-    if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
-        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
-        m->intermediate % 8 != 0 || m->max_len <= 0)
-        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: bad model dimensions");
-    if (st->batch < 2 || st->batch > 64) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: batch %d outside 2..64", st->batch);
-    if (m->hidden > OB_DEC_MAXV * OB_DEC_THREADS * 8 || m->intermediate > OB_DEC_MAXV * OB_DEC_THREADS * 8)
-        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: hidden / intermediate beyond %d", OB_DEC_MAXV * OB_DEC_THREADS * 8);
-    if (!m->layers || !m->embed || !m->final_norm_w || !m->rope_cos || !m->rope_sin || !st->tokens || !st->pos ||
-        !st->hres0 || !st->hres1 || !st->x || !st->act || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
-        !st->u_o || !st->u_gate || !st->u_up || !st->u_down)
-        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer");
-    hipStream_t s = (hipStream_t)stream;
     const int B = st->batch, H = m->hidden, I = m->intermediate, D = m->head_dim;
     const int NQ = m->n_heads * D, NK = m->n_kv_heads * D;
     if (NQ != H) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: n_heads * head_dim != hidden");
@@ -1045,8 +1036,10 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         const int64_t kk[7] = {H, H, H, NQ, H, H, I}, nn[7] = {NQ, NK, NK, H, I, I, H};
         for (int i = 0; sk3 && i < 7; ++i) {
             const onebit_proj_t &p = *pp[i];
+            // the rows each launch really DMAs from: the pre-scaled copies (q, k, v / gate, up), attn_out (o), act (down)
+            const void *rows = i < 3 ? (const void *)xs[i] : i == 3 ? (const void *)st->attn_out : i < 6 ? (const void *)xs[i - 4] : (const void *)st->act;
             sk3 = p.weight && p.input_factor && p.weight_scale && p.K == kk[i] && p.N == nn[i] &&
-                  ob_skinny3_shape_ok(p.weight, p.ldw_bytes, xs[0], kk[i], B, i == 6 ? kk[i] / 2 : kk[i], nn[i]);
+                  ob_skinny3_shape_ok(p.weight, p.ldw_bytes, rows, kk[i], B, i == 6 ? kk[i] / 2 : kk[i], nn[i]);
         }
     }
     const bool down_parts = sk3 || splitk_down;
@@ -1152,9 +1145,11 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         ObAttnArgs at = {};
         at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
         at.cos = (const _Float16 *)m->rope_cos; at.sin = (const _Float16 *)m->rope_sin;
-        at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
+        at.slot_stride = (long long)m->n_kv_heads * m->max_len * D;
+        at.kcache = (_Float16 *)L.k_cache + (size_t)slot0 * at.slot_stride; at.vcache = (_Float16 *)L.v_cache + (size_t)slot0 * at.slot_stride;
+        at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
-        at.ln_eps = m->ln_eps; at.slot_stride = (long long)m->n_kv_heads * m->max_len * D;
+        at.ln_eps = m->ln_eps;
         const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
@@ -1212,7 +1207,89 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     else nf.u_prev = (const _Float16 *)st->u_down;
     nf.x = (_Float16 *)st->x; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
     OB_LAUNCH_NORM(false, H, dim3(B), s, nf);
-    if ((rc = ob_launch_status("decode_step_batched(final norm)"))) return rc;
+    return ob_launch_status("decode_step_batched(final norm)");
+}
+
+// side streams / events for the chain split of the batched step (per device; created on the first call, which must
+// not be inside a stream capture -- callers warm up once before capturing, as every graph user of this library does)
+struct ObChainCtx { hipStream_t side[3]; hipEvent_t fork, join[3]; bool ok; };
+static ObChainCtx *ob_chain_ctx()
+{
+    static ObChainCtx ctx[OB_MAX_DEVICES] = {};
+    ObChainCtx &c = ctx[ob_device_index()];
+    if (!c.ok) {
+        bool good = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; good && i < 3; ++i)
+            good = hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&c.join[i], hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); return nullptr; }
+        c.ok = true;
+    }
+    return &c;
+}
+
+extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
+{
+    if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
+    if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
+        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
+        m->intermediate % 8 != 0 || m->max_len <= 0)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: bad model dimensions");
+    if (st->batch < 2 || st->batch > 64) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: batch %d outside 2..64", st->batch);
+    if (m->hidden > OB_DEC_MAXV * OB_DEC_THREADS * 8 || m->intermediate > OB_DEC_MAXV * OB_DEC_THREADS * 8)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: hidden / intermediate beyond %d", OB_DEC_MAXV * OB_DEC_THREADS * 8);
+    if (!m->layers || !m->embed || !m->final_norm_w || !m->rope_cos || !m->rope_sin || !st->tokens || !st->pos ||
+        !st->hres0 || !st->hres1 || !st->x || !st->act || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
+        !st->u_o || !st->u_gate || !st->u_up || !st->u_down)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = st->batch, H = m->hidden, I = m->intermediate;
+    const int NQ = m->n_heads * m->head_dim, NK = m->n_kv_heads * m->head_dim;
+    // Independent chains: the B sequences as `chains` groups of consecutive slots, each group's layer chain on its own
+    // stream (forked from / joined to `stream`; under capture: parallel graph branches), ONE lm_head over all rows at the
+    // end.  A chain is 8 dependent launches per layer on an otherwise idle chip -- one chain's GEMM fills the other's
+    // ramps, tails, row kernels and attention; the second read of a layer's packed rows comes from L2 / Infinity Cache.
+    // Per-row results do not depend on the grouping (a row's sums never mix with other rows').
+    static const int chains_env = getenv("OB_BATCH_CHAINS") ? atoi(getenv("OB_BATCH_CHAINS")) : 0;
+    int chains = chains_env > 0 ? chains_env : (st->chains > 0 ? st->chains : 1);
+    if (chains > 4) chains = 4;
+    while (chains > 1 && B / chains < 2) --chains;
+    int rc;
+    if (chains <= 1) {
+        if ((rc = ob_batched_layers(m, st, 0, s))) return rc;
+    } else {
+        ObChainCtx *cx = ob_chain_ctx();
+        if (!cx) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: cannot create the side streams of the chain split");
+        const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
+        if (hipEventRecord(cx->fork, s) != hipSuccess) return ob_launch_status("decode_step_batched(fork)");
+        const int per = B / chains;
+        for (int c = 0; c < chains; ++c) {
+            const int r0 = c * per, nb = c == chains - 1 ? B - r0 : per;
+            onebit_batch_state_t v = *st;
+            v.batch = nb;
+            v.tokens = st->tokens + r0; v.pos = st->pos + r0;
+            auto row = [&](void *p, size_t width) -> void * { return p ? (void *)((_Float16 *)p + (size_t)r0 * width) : nullptr; };
+            v.hres0 = row(st->hres0, H); v.hres1 = row(st->hres1, H); v.x = row(st->x, H); v.act = row(st->act, I);
+            v.u_q = row(st->u_q, NQ); v.u_k = row(st->u_k, NK); v.u_v = row(st->u_v, NK); v.attn_out = row(st->attn_out, NQ);
+            v.u_o = row(st->u_o, H); v.u_gate = row(st->u_gate, I); v.u_up = row(st->u_up, I); v.u_down = row(st->u_down, H);
+            v.qkv_stats = st->qkv_stats ? st->qkv_stats + (size_t)r0 * (fq + 2 * fk) : nullptr;     // a group's [3][nb] blocks
+            v.x_scaled = st->x_scaled ? (void *)((_Float16 *)st->x_scaled + (size_t)r0 * 3 * H) : nullptr;   // a group's [3][nb][H]
+            hipStream_t cs = c == 0 ? s : cx->side[c - 1];
+            if (c > 0 && hipStreamWaitEvent(cs, cx->fork, 0) != hipSuccess) return ob_launch_status("decode_step_batched(fork wait)");
+            if ((rc = ob_batched_layers(m, &v, r0, cs))) return rc;
+            if (c > 0) {
+                if (hipEventRecord(cx->join[c - 1], cs) != hipSuccess || hipStreamWaitEvent(s, cx->join[c - 1], 0) != hipSuccess)
+                    return ob_launch_status("decode_step_batched(join)");
+            }
+        }
+    }
+    return ob_batched_head(m, st, s);
+}
+
+static int ob_batched_head(const onebit_model_t *m, const onebit_batch_state_t *st, hipStream_t s)
+{
+    const int B = st->batch, H = m->hidden;
+    int rc;
     if (!st->next_tokens) return 0;
     // batched lm_head + greedy sampling
     if (!m->lm_head || m->vocab <= 0 || !st->part_val || !st->part_idx)

@@ -55,7 +55,7 @@ class _BatchState(ctypes.Structure):
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp),
-                ("x_scaled", _vp)]
+                ("x_scaled", _vp), ("chains", _i32)]
 
 
 class _FusedIn(ctypes.Structure):
@@ -303,7 +303,7 @@ class BatchedDecodeStep:
     ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
 
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
-                 keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True):
+                 keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True, chains: int = 0):
         cfg = model.config
         p = model.lm_head.weight
         if not p.is_cuda:
@@ -346,7 +346,8 @@ class BatchedDecodeStep:
         self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
-                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None, None)
+                                  b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None, None,
+                                  int(chains))
         # room for the consumers' pre-scaled rows fp16(x * input_factor): the projections then take the LDS-DMA skinny GEMM
         if prescaled_rows:
             self._x_scaled = torch.zeros(3, batch, H, dtype=f16, device=dev)

@@ -12,8 +12,15 @@ seed, 52 MB packed); the fixture holds only token ids and the reference's logits
   long    one 4096-token prompt (every projection of this width takes the LDS-DMA prefill GEMM from T = 4096 in the build), fp16 and fp32: logits of
           16 positions (the last 8 and 8 seeded ones)
 
-Output: tests/golden/model_wide_c.npz (data only, ~1 MB).  Usage (from the repo root):
-  PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/transformers/src:. python tests/golden/gen_goldens_model_wide.py
+Config "d" (round 4) = the same widths at FULL DEPTH: 32 layers (the whole LLaMA-7B decoder stack,
+modeling_bitllama.py:1287-1319 layer loop; vocabulary 512), seed 11 — pins error growth through 32 x 7
+LayerNorm-terminated projections:
+
+  short   12-token prompt: prefill logits + 2 incremental decode steps, fp16 and fp32
+  batch   8 sequences x 6 prompt tokens in one batched reference call + 2 batched decode steps, fp16 and fp32
+
+Output: tests/golden/model_wide_c.npz / model_wide_d.npz (data only).  Usage (from the repo root):
+  PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/transformers/src:. python tests/golden/gen_goldens_model_wide.py [c|d] [parts...]
 """
 import importlib.metadata as md
 import os
@@ -38,25 +45,35 @@ sys.path.insert(0, ROOT)
 from onebit_amd.llama import OneBitLlamaConfig, synthetic_state_dict  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-KW = dict(vocab_size=512, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
-          num_attention_heads=32, max_position_embeddings=4352)
-SEED = 7
+CONFIGS = {
+    "c": dict(kw=dict(vocab_size=512, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+                      num_attention_heads=32, max_position_embeddings=4352),
+              seed=7, parts=["short", "batch", "long"], steps=4, batch=(32, 6), batch_steps=3),
+    "d": dict(kw=dict(vocab_size=512, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                      num_attention_heads=32, max_position_embeddings=256),
+              seed=11, parts=["short", "batch"], steps=2, batch=(8, 6), batch_steps=2),
+}
 LONG = 4096
 
 
-def main(parts):
+def main(name, parts):
+    C = CONFIGS[name]
+    KW, SEED = C["kw"], C["seed"]
+    parts = parts or C["parts"]
     cfg = OneBitLlamaConfig(**KW)
-    path = f"{OUT}/model_wide_c.npz"
+    path = f"{OUT}/model_wide_{name}.npz"
     out = dict(np.load(path)) if os.path.exists(path) else {}
     out.update({"cfg_" + k: np.array(v) for k, v in KW.items()})
     out["seed"] = np.array(SEED)
     sd16 = synthetic_state_dict(cfg, seed=SEED, dtype=torch.float16)
     g = torch.Generator().manual_seed(2024)
     ids = torch.randint(0, cfg.vocab_size, (1, 12), generator=g)
-    bids = torch.randint(0, cfg.vocab_size, (32, 6), generator=g)
+    bids = torch.randint(0, cfg.vocab_size, C["batch"], generator=g)
     lids = torch.randint(0, cfg.vocab_size, (1, LONG), generator=g)
     lpos = np.array(sorted(set(range(LONG - 8, LONG)) | set(np.random.default_rng(5).integers(0, LONG - 8, 8).tolist())))
-    out["input_ids"], out["batch_ids"], out["long_ids"], out["long_pos"] = ids.numpy(), bids.numpy(), lids.numpy(), lpos
+    out["input_ids"], out["batch_ids"] = ids.numpy(), bids.numpy()
+    if "long" in C["parts"]:
+        out["long_ids"], out["long_pos"] = lids.numpy(), lpos
     for dt, dn in ((torch.float16, "f16"), (torch.float32, "f32")):
         model = BitLlamaForCausalLMInf(BitLlamaConfig(**KW))
         sd = {k: (v if v.dtype == torch.int8 else v.to(dt)) for k, v in sd16.items()}
@@ -71,7 +88,7 @@ def main(parts):
                 past = o.past_key_values
                 tok = o.logits[:, -1].argmax(-1, keepdim=True)
                 toks, step_logits = [tok], []
-                for _ in range(4):
+                for _ in range(C["steps"]):
                     o = model(tok, past_key_values=past, use_cache=True)
                     past = o.past_key_values
                     step_logits.append(o.logits.float().numpy())
@@ -87,7 +104,7 @@ def main(parts):
                 lg = [o.logits[:, -1:].float().numpy()]
                 tok = o.logits[:, -1].argmax(-1, keepdim=True)
                 btoks = [tok]
-                for _ in range(3):
+                for _ in range(C["batch_steps"]):
                     o = model(tok, past_key_values=past, use_cache=True)
                     past = o.past_key_values
                     lg.append(o.logits.float().numpy())
@@ -108,4 +125,6 @@ def main(parts):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    main(sys.argv[1:] or ["short", "batch", "long"])
+    args = sys.argv[1:]
+    name = args.pop(0) if args and args[0] in CONFIGS else "c"
+    main(name, args)
