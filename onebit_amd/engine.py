@@ -12,6 +12,7 @@ into the same preallocated KV cache.
 """
 from __future__ import annotations
 
+import copy
 import ctypes
 from typing import List
 
@@ -97,11 +98,26 @@ def fused_gemv(mods, outs, prologue, rms_eps=1e-6, ln_eps=1e-5, stats_out=None, 
     _lib.check(rc, "onebit_fused_gemv")
 
 
+def fp16_view(model: OneBitLlamaForCausalLM) -> OneBitLlamaForCausalLM:
+    """The model the fused engines run: every floating parameter in fp16, the packed int8 weights SHARED with
+    ``model`` (not copied).  An fp16 model is returned as is.  This is what the reference's
+    ``from_pretrained(..., torch_dtype=torch.float16)`` does to the released FP32 checkpoints
+    (/root/reference/checkpoints/README.md:10; modeling_utils.py:696 casts floating parameters only), done once
+    at engine build instead of making the caller find out; the caller's fp32 model is left untouched."""
+    if all(p.dtype == torch.float16 for p in model.parameters() if p.is_floating_point()):
+        return model
+    memo = {id(p): p for p in model.parameters() if not p.is_floating_point()}
+    return copy.deepcopy(model, memo).half()
+
+
 def _proj(m: BitLinearInf) -> _Proj:
     if m.bias is not None:
-        raise ValueError("DecodeEngine: projections with bias are not supported (LLaMA uses bias=False)")
+        raise ValueError(
+            "the fused decode engines cover projections without bias (config.attention_bias=False, the default of "
+            "configuration_bitllama.py and of every released OneBit checkpoint); for a checkpoint with attention_bias=True "
+            "decode through the module path instead: model.generate(...) or ContinuousBatcher(..., native=False)")
     if m.weight_scale.dtype != torch.float16 or m.input_factor.dtype != torch.float16:
-        raise ValueError("DecodeEngine needs an fp16 model (model.half())")
+        raise ValueError("the fused decode engines run fp16 parameters: pass the model through engine.fp16_view()")
     if m.in_features % 32 != 0:
         raise ValueError(f"DecodeEngine: in_features={m.in_features} is not a multiple of 32; use the module path")
     w = m.weight
@@ -142,11 +158,10 @@ class DecodeEngine:
         """``long_context_from``: position from which a step uses the split-KV attention graph (two
         launches per layer over head x split); below it one workgroup per head is faster.  0 disables."""
         cfg = model.config
-        p = model.lm_head.weight
-        if not p.is_cuda:
+        if not model.lm_head.weight.is_cuda:
             raise RuntimeError("DecodeEngine needs the model on a ROCm GPU (no CPU fallback)")
-        if p.dtype != torch.float16:
-            raise ValueError("DecodeEngine needs an fp16 model")
+        model = fp16_view(model)        # an fp32 checkpoint: floating parameters cast once, packed weights shared
+        p = model.lm_head.weight
         self.model, self.cfg, self.dev = model, cfg, p.device
         self.lib = _lib.load()
         if not hasattr(self.lib, "onebit_decode_step"):
@@ -305,11 +320,10 @@ class BatchedDecodeStep:
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
                  keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True, chains: int = 0):
         cfg = model.config
-        p = model.lm_head.weight
-        if not p.is_cuda:
+        if not model.lm_head.weight.is_cuda:
             raise RuntimeError("BatchedDecodeStep needs the model on a ROCm GPU (no CPU fallback)")
-        if p.dtype != torch.float16:
-            raise ValueError("BatchedDecodeStep needs an fp16 model")
+        model = fp16_view(model)        # an fp32 checkpoint: floating parameters cast once, packed weights shared
+        p = model.lm_head.weight
         if not 2 <= batch <= 64:
             raise ValueError("batch must be in 2..64")
         if max_len > cfg.max_position_embeddings:

@@ -457,6 +457,9 @@ def synthetic_state_dict(config: OneBitLlamaConfig, seed: int = 0, dtype=torch.f
                                                device=device).view(torch.int8)
             sd[pre + "input_factor"] = scale(K, g)
             sd[pre + "weight_scale"] = scale(N, g)
+            if config.attention_bias and name.startswith("self_attn."):      # bias=config.attention_bias, modeling_bitllama.py:451-454
+                gb = torch.Generator(device=device).manual_seed(seed + 1000 * l + p + 500)     # own stream: other draws unchanged
+                sd[pre + "bias"] = (0.1 * torch.randn(N, generator=gb, device=device)).to(dtype)
         sd[f"model.layers.{l}.input_layernorm.weight"] = torch.ones(H, dtype=dtype, device=device)
         sd[f"model.layers.{l}.post_attention_layernorm.weight"] = torch.ones(H, dtype=dtype, device=device)
     g = torch.Generator(device=device).manual_seed(seed + 999_983)

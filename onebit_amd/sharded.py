@@ -18,6 +18,7 @@ On MI355X the backend "nccl" is RCCL over xGMI; tests run the identical control 
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import Callable, Optional, Tuple
 
@@ -326,3 +327,101 @@ def n_sharded_forward(shard: NShard, x: torch.Tensor, group=None, gather: bool =
     parts = torch.empty((world * T, n), dtype=y.dtype, device=y.device)      # rank-major concatenation
     dist.all_gather_into_tensor(parts, y.contiguous(), group=group)
     return parts.view(world, T, n).permute(1, 0, 2).reshape(T, N)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Static-shape greedy decode: one token per step with the token id and the position ON THE DEVICE and every tensor
+# shape fixed, so that a whole step of a K-sharded model -- 7 partial GEMVs + 7 all-reduces per layer -- is ONE HIP
+# graph (RCCL collectives are stream-ordered and capturable).  BASELINE config 4 measures the exchange; run eagerly the
+# same step is ~600 Python-issued launches per token and measures the host instead.  Works on any model of this package
+# (sharded or not: with world 1 it is the single-GPU module arithmetic under a graph).
+# Attention runs over the WHOLE preallocated cache with positions beyond the current one masked (additive
+# finfo.min, the reference's mask form, modeling_bitllama.py:1256-1262): their probabilities are exactly 0.
+# ---------------------------------------------------------------------------------------------------
+class StaticShapeDecoder:
+    def __init__(self, model: torch.nn.Module, max_len: int, use_graph: bool = True):
+        from .llama import _rotate_half
+        self._rot = _rotate_half
+        self.model, self.cfg = model, model.config
+        p = model.lm_head.weight
+        self.dev, self.dtype = p.device, p.dtype
+        self.max_len = int(max_len)
+        self.cache = model.new_cache(1, self.max_len)
+        self.cos, self.sin = model._rope_tables(self.dev, self.dtype, self.max_len)
+        self.tok = torch.zeros((1, 1), dtype=torch.long, device=self.dev)
+        self.pos = torch.zeros(1, dtype=torch.long, device=self.dev)
+        self.out_tokens = torch.zeros(self.max_len, dtype=torch.long, device=self.dev)
+        self._ar = torch.arange(self.max_len, device=self.dev)
+        self.use_graph = bool(use_graph) and p.is_cuda
+        self.graph = None
+        self.steps = 0
+
+    @torch.no_grad()
+    def prime(self, prompt: torch.Tensor) -> int:
+        """Prompt through the module path into the static cache; arms token / position.  Returns the first new token."""
+        S = prompt.shape[1]
+        if S + 1 > self.max_len:
+            raise ValueError("prompt longer than max_len")
+        self.cache.length = 0
+        logits = self.model(prompt.to(self.dev), self.cache)
+        self.tok.copy_(logits[:, -1].argmax(-1, keepdim=True))
+        self.pos.fill_(S)
+        self.steps = S
+        return int(self.tok.item())
+
+    @torch.no_grad()
+    def _step(self):
+        m, cfg = self.model.model, self.cfg
+        H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        pos = self.pos
+        h = m.embed_tokens(self.tok)                                        # [1, 1, hidden]
+        c = self.cos.index_select(0, pos)[None, None]                       # [1, 1, 1, D]
+        s = self.sin.index_select(0, pos)[None, None]
+        mask = torch.where(self._ar > pos, torch.finfo(self.dtype).min, 0.0).to(self.dtype)[None, None, None]   # [1,1,1,max_len]
+        for layer, (kc, vc) in zip(m.layers, self.cache.layers):
+            att = layer.self_attn
+            x = layer.input_layernorm(h)
+            q = att.q_proj(x).view(1, 1, H, D).transpose(1, 2)
+            k = att.k_proj(x).view(1, 1, Hkv, D).transpose(1, 2)
+            v = att.v_proj(x).view(1, 1, Hkv, D).transpose(1, 2)
+            q = (q * c) + (self._rot(q) * s)
+            k = (k * c) + (self._rot(k) * s)
+            kc.index_copy_(2, pos, k)
+            vc.index_copy_(2, pos, v)
+            keys, vals = kc, vc
+            if Hkv != H:
+                keys, vals = keys.repeat_interleave(H // Hkv, dim=1), vals.repeat_interleave(H // Hkv, dim=1)
+            w = torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(D) + mask
+            w = torch.nn.functional.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+            o = torch.matmul(w, vals).transpose(1, 2).reshape(1, 1, H * D)
+            h = h + att.o_proj(o)
+            h = h + layer.mlp(layer.post_attention_layernorm(h))
+        logits = self.model.lm_head(m.norm(h)).float()
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        self.out_tokens.index_copy_(0, pos, nxt.view(1))
+        self.tok.copy_(nxt)
+        self.pos.add_(1)
+        self._logits = logits
+
+    def step(self):
+        if self.steps >= self.max_len:
+            raise RuntimeError("StaticShapeDecoder: KV cache full")
+        if not self.use_graph:
+            self._step()
+        else:
+            if self.graph is None:
+                # warm up on a side stream (communicators, allocator pools), restoring the state it advanced
+                tok0, pos0 = self.tok.clone(), self.pos.clone()
+                side = torch.cuda.Stream(self.dev)
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    self._step()
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+                self.tok.copy_(tok0); self.pos.copy_(pos0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step()
+                self.tok.copy_(tok0); self.pos.copy_(pos0)                  # capture does not execute; state as before
+                self.graph = g
+            self.graph.replay()
+        self.steps += 1

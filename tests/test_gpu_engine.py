@@ -263,3 +263,61 @@ def test_fused_gemv_propagates_non_finite_activations():
         xb[5000] = bad
         fused_gemv([m], [out], PRO_PLAIN, xin=xb)
         assert torch.isnan(out).all()
+
+
+def test_engine_accepts_fp32_checkpoint(golden_dir):
+    """The released OneBit checkpoints are FP32 (/root/reference/checkpoints/README.md:10).  The fused engines cast the
+    floating parameters once at build -- what from_pretrained(torch_dtype=float16) does (modeling_utils.py:696) --
+    sharing the packed int8 weights, and leave the caller's fp32 model untouched: an engine built from the fp32 model
+    gives the logits of one built from the fp16 model, bit for bit, and they meet the reference's fp16 decode logits."""
+    from onebit_amd.engine import BatchedDecodeStep, DecodeEngine, fp16_view
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(golden_dir, "model_tiny_b.npz"))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
+    m32 = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float32)
+    m32.load_state_dict({k: (v if v.dtype == torch.int8 else v.float()) for k, v in sd.items()})
+    m32 = m32.to(dev).eval()
+    m16 = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float16)
+    m16.load_state_dict(sd)
+    m16 = m16.to(dev).eval()
+    view = fp16_view(m32)
+    assert view is not m32 and fp16_view(m16) is m16
+    q32, qv = m32.model.layers[0].self_attn.q_proj, view.model.layers[0].self_attn.q_proj
+    assert qv.weight.data_ptr() == q32.weight.data_ptr()                   # packed weights shared, not copied
+    assert q32.weight_scale.dtype == torch.float32 and qv.weight_scale.dtype == torch.float16
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    toks = z["greedy_f16"][0]
+    ref16, ref32 = z["decode_logits_f16"][0], z["decode_logits_f32"][0]
+    tol = max(2.0 * np.abs(ref16 - ref32).max(), 2e-3 * np.abs(ref32).max())
+    got = {}
+    for name, model in (("fp32", m32), ("fp16", m16)):
+        eng = DecodeEngine(model, max_len=32)
+        eng.prefill(ids)
+        out = []
+        for i in range(3):
+            eng.set_state(int(toks[i]), ids.shape[1] + i)
+            eng.step()
+            out.append(eng.logits().cpu().numpy())
+        got[name] = np.stack(out)
+        assert np.abs(got[name] - ref16[:3]).max() <= tol
+    assert np.array_equal(got["fp32"], got["fp16"])
+    assert m32.lm_head.weight.dtype == torch.float32                       # the caller's model was not modified
+    # the batched step takes the fp32 model the same way
+    cache = view.new_cache(2, 16)
+    BatchedDecodeStep(m32, cache.layers, 2, 16)
+
+
+def test_engine_bias_checkpoint_names_the_remedy(golden_dir):
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=96, hidden_size=128, intermediate_size=352, num_hidden_layers=1, num_attention_heads=2,
+                            max_position_embeddings=64, attention_bias=True)
+    model = build_synthetic_model(cfg, seed=1, device=dev)
+    assert model.model.layers[0].self_attn.q_proj.bias is not None
+    with pytest.raises(ValueError, match="module path"):
+        DecodeEngine(model, max_len=32)
+    out = model.generate(torch.tensor([[1, 2, 3]], device=dev), max_new_tokens=2)      # the named remedy works
+    assert out.shape == (1, 5)

@@ -160,6 +160,56 @@ def test_k_sharded_model_decode_gloo(golden_dir, world, mode):
     assert err <= 2e-3 * max(1.0, scale), (err, scale)
 
 
+def _static_worker(rank, world, port, golden_dir, out):
+    """StaticShapeDecoder (device-side token / position, static shapes: the graph-capturable config-4 step) on the
+    K-sharded tiny model: greedy tokens and logits against the reference's recorded decode."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM
+        from onebit_amd.sharded import StaticShapeDecoder, shard_model_k
+        z = np.load(os.path.join(golden_dir, "model_tiny_b.npz"))
+        kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+        model = OneBitLlamaForCausalLM(OneBitLlamaConfig(**kw), torch.float32)
+        model.load_state_dict({k[3:]: (torch.from_numpy(z[k]) if z[k].dtype == np.int8 else torch.from_numpy(z[k]).float())
+                               for k in z.files if k.startswith("sd_")})
+        shard_model_k(model.eval(), rank, world, mode="allreduce", partial_fn=_np_partial, epilogue_fn=_np_epilogue)
+        ids = torch.from_numpy(z["input_ids"])
+        dec = StaticShapeDecoder(model, max_len=ids.shape[1] + 8, use_graph=False)
+        toks = z["greedy_f32"][0]
+        first = dec.prime(ids)
+        assert first == int(toks[0])
+        errs = []
+        for i in range(4):
+            dec.step()
+            errs.append(float(np.abs(dec._logits[0, -1].numpy() - z["decode_logits_f32"][0][i]).max()))
+            assert int(dec.tok.item()) == int(toks[i + 1]) and int(dec.pos.item()) == ids.shape[1] + i + 1
+        assert dec.out_tokens[ids.shape[1]:ids.shape[1] + 4].tolist() == [int(t) for t in toks[1:5]]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, errs)
+        assert all(g == errs for g in gathered)
+        if rank == 0:
+            out.put((max(errs), float(np.abs(z["decode_logits_f32"]).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_static_shape_decoder_k_sharded_gloo(golden_dir):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_static_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    err, scale = q.get(timeout=5)
+    assert err <= 2e-3 * max(1.0, scale), (err, scale)
+
+
 def _np_rows_u(shard, x):
     """Oracle stand-in for hip_rows_u: pre-LayerNorm u of the rank's rows."""
     from oracle.oracle import np_forward_f16, np_forward_f32
