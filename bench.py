@@ -64,7 +64,7 @@ def spawn_command(gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -76,10 +76,11 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-serve", action="store_true", help="skip the continuous-batching (config 5) field")
+    ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-caller field (perplexity windows + ragged loglikelihood batch)")
     ap.add_argument("--no-k-sharded-decode", action="store_true",
                     help="skip BASELINE config 4 (LLaMA-13B shapes, module-path decode with every 1-bit layer K-sharded "
                          "over the ranks, one all-reduce per BitLinearInf call; extra JSON field, not the headline value)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def algorithmic_bytes(T, K, N):
@@ -111,24 +112,37 @@ def _chain_us(launch_layer, layers, dev, min_launches=512):
     """us per launch of `launch_layer(layer)` captured once per decoder layer (distinct weights) in a
     HIP graph and replayed; HIP events on the replay stream.  Includes the dependent-kernel boundary
     every launch of a decode chain pays."""
+    us, n = _chain_total_us([launch_layer], layers, dev, min_launches)
+    return us / len(layers), n
+
+
+def _chain_total_us(fns, layers, dev, min_launches=512, rounds=5):
+    """us per REPLAY of the chain `for layer: for fn in fns: fn(layer)` (one HIP graph), median of `rounds` timed
+    batches of replays, and the number of launches timed per batch."""
     for layer in layers:
-        launch_layer(layer)
+        for fn in fns:
+            fn(layer)
     torch.cuda.synchronize(dev)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for layer in layers:
-            launch_layer(layer)
+            for fn in fns:
+                fn(layer)
     for _ in range(8):                      # settle clocks / TLBs on the new buffers before timing
         graph.replay()
     torch.cuda.synchronize(dev)
-    reps = max(2, min_launches // len(layers))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        graph.replay()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e3 / (reps * len(layers)), reps * len(layers)
+    nl = len(layers) * len(fns)
+    reps = max(2, min_launches // nl)
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return statistics.median(ts), reps * nl
 
 
 def measure_roofline(model, dev, ms_per_token, tok_bytes):
@@ -182,13 +196,23 @@ def measure_roofline(model, dev, ms_per_token, tok_bytes):
                 traffic = tj.get("bytes_per_launch", {})
         except Exception:
             traffic = {}
+    # Cache honesty (>= 360 MB of distinct weights per chain): the four launches are timed IN LAYER ORDER
+    # over the whole model -- one graph of qkv, o, gate_up, down for each of the L layers (810 MB of packed rows at 7B,
+    # 3x the Infinity Cache; a chain of one kind alone cycles through 68-361 MB and may be served from it) -- and a
+    # launch's time is what the chain loses when that launch is left out: (T_all - T_without_k) / L.
+    order = ["qkv", "o", "gate_up", "down"]
+    t_all, n_all = _chain_total_us([kinds[k][0] for k in order], layers, dev)
     per = []
-    for name, (fn, nbytes, what) in kinds.items():
-        us, n = _chain_us(fn, layers, dev)
+    for name in order:
+        fn, nbytes, what = kinds[name]
+        t_wo, _ = _chain_total_us([kinds[k][0] for k in order if k != name], layers, dev)
+        us = max((t_all - t_wo) / L, 1e-3)
+        us_iso, n_iso = _chain_us(fn, layers, dev)
         gbs = nbytes / (us * 1e-6) / 1e9
         per.append({"kernel": name, "what": what, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 3),
                     "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "us_per_token": round(us * L, 1),
-                    "traffic": traffic.get(name), "launches": n})
+                    "traffic": traffic.get(name), "launches": n_all // len(order),
+                    "isolated_chain_us": round(us_iso, 3)})
     dom = max(per, key=lambda r: r["us_per_token"])
     gemv_us = sum(r["us_per_token"] for r in per)
     whole = tok_bytes / (ms_per_token * 1e-3) / 1e9
@@ -196,6 +220,10 @@ def measure_roofline(model, dev, ms_per_token, tok_bytes):
             "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
             "launches": dom["launches"], "distinct_weight_sets": L, "selection": "largest time per token of the four GEMV launches",
+            "timing": "HIP events over graph replays of the four launches in LAYER ORDER over all %d layers' weights (%.0f MB of "
+                      "packed rows per replay); a launch's time = (chain - chain without it) / layers; isolated_chain_us = "
+                      "the same launch as a chain of its own kind (rounds 1-3 figure)" % (L, sum(k[1] for k in kinds.values()) * L / 1e6),
+            "layer_chain_us": round(t_all / L, 3),
             "per_kernel": per,
             "whole_token": {"algorithmic_bytes": tok_bytes, "ms": round(ms_per_token, 4), "achieved": round(whole, 1),
                             "frac": round(whole / HBM_PEAK_GBS, 4),
@@ -279,36 +307,81 @@ def measure_prefill_sharded(cfg, dev, world, rank):
 
 
 def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
-    """BASELINE config 4: greedy decode with every BitLinearInf K-sharded (onebit_amd/sharded.py,
-    KShardedBitLinear): partial GEMV on the rank's K slice, all-reduce of the [1, N] fp32 partials,
-    g + LayerNorm everywhere.  Module path (torch glue, no HIP graph): the point is the exchange."""
+    """BASELINE config 4 (LLaMA-13B shapes): greedy decode with every BitLinearInf K-sharded (onebit_amd/sharded.py,
+    KShardedBitLinear): partial GEMV on the rank's K slice, all-reduce of the [1, N] fp32 partials, g + LayerNorm
+    everywhere.  Three figures:
+      single_gpu_engine  the fused DecodeEngine on the WHOLE 13B checkpoint on one GPU -- the honest N = 1 line any
+                         sharded figure has to be compared with (every rank runs it on its own copy);
+      graph              the sharded step under ONE HIP graph with the all-reduces captured (StaticShapeDecoder:
+                         device-side token / position, static shapes) -- measures the exchange, not Python;
+      eager              the same sharded modules driven from Python (the exchange test-bed of rounds 1-3; ~600
+                         host-issued launches per token: host-bound, NOT a baseline)."""
     import torch.distributed as dist
     from onebit_amd.llama import build_synthetic_model
-    from onebit_amd.sharded import shard_model_k
+    from onebit_amd.sharded import StaticShapeDecoder, shard_model_k
     model = build_synthetic_model(cfg, seed=4242, device=dev)          # same checkpoint on every rank
-    shard_model_k(model, rank, world, mode="allreduce")
-    torch.cuda.empty_cache()
     g = torch.Generator(device="cpu").manual_seed(7)
     prompt = torch.randint(0, cfg.vocab_size, (1, prompt_len), generator=g).to(dev)
-    cache = model.new_cache(1, prompt_len + steps + 4)
-    tok = model(prompt, cache)[:, -1].argmax(-1, keepdim=True)
-    for _ in range(2):
-        tok = model(tok, cache)[:, -1].argmax(-1, keepdim=True)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tok = model(tok, cache)[:, -1].argmax(-1, keepdim=True)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    return {"k_shards": world, "exchange": "all_reduce(fp32 [1,N]) per BitLinearInf call", "steps": steps,
-            "ms_per_token": round(dt / steps * 1e3, 3), "tokens_per_s": round(steps / dt, 2),
-            "collectives_per_token": 7 * cfg.num_hidden_layers if world > 1 else 0, "path": "module (eager)"}
+    max_len = prompt_len + 2 * steps + 16
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(step_fn, warm):
+        for _ in range(warm):
+            step_fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    out = {"k_shards": world, "exchange": "all_reduce(fp32 [1,N]) per BitLinearInf call", "steps": steps,
+           "collectives_per_token": 7 * cfg.num_hidden_layers if world > 1 else 0}
+    try:                                                               # the fused engine on the unsharded checkpoint
+        from onebit_amd.engine import DecodeEngine
+        eng = DecodeEngine(model, max_len=max_len)
+        eng.prefill(prompt)
+        dt = timed(eng.step, 4)
+        out["single_gpu_engine"] = {"ms_per_token": round(dt / steps * 1e3, 4), "tokens_per_s": round(steps / dt, 1),
+                                    "engine": "onebit_decode_step (HIP graph), whole checkpoint on one GPU",
+                                    "note": "the N = 1 line sharded decode compares with"}
+        del eng
+    except Exception as e:
+        out["single_gpu_engine"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    shard_model_k(model, rank, world, mode="allreduce")
+    torch.cuda.empty_cache()
+    try:                                                               # sharded step as one HIP graph, collectives captured
+        dec = StaticShapeDecoder(model, max_len=max_len, use_graph=True)
+        dec.prime(prompt)
+        dt = timed(dec.step, 3)
+        out["graph"] = {"ms_per_token": round(dt / steps * 1e3, 3), "tokens_per_s": round(steps / dt, 2),
+                        "path": "StaticShapeDecoder: module kernels + RCCL all-reduces replayed as one HIP graph"}
+        del dec
+    except Exception as e:
+        out["graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    cache = model.new_cache(1, max_len)
+    state = {"tok": model(prompt, cache)[:, -1].argmax(-1, keepdim=True)}
+
+    def eager_step():
+        state["tok"] = model(state["tok"], cache)[:, -1].argmax(-1, keepdim=True)
+    dt = timed(eager_step, 2)
+    out["eager"] = {"ms_per_token": round(dt / steps * 1e3, 3), "tokens_per_s": round(steps / dt, 2),
+                    "path": "module path driven from Python (host-bound exchange test-bed, not a baseline)"}
+    # headline fields of this object: the graph figure when it exists
+    best = out["graph"] if "error" not in out["graph"] else out["eager"]
+    out["ms_per_token"], out["tokens_per_s"], out["path"] = best["ms_per_token"], best["tokens_per_s"], best["path"]
+    return out
 
 
 def measure_continuous_batch(model, dev, slots=32, steps=40):
@@ -391,6 +464,58 @@ def measure_prefill_model_tp(model, dev, world, rank, B=8, S=2048, tp_kwargs=Non
             "bytes_per_exchange_per_rank": (T * H * 4 + T * H * 2) if world > 1 else 0,
             "attention": "onebit_attention_prefill on the local heads", "logits": "own token rows only (not gathered)",
             "glue": "fused row kernels (onebit_rows_qkv_rope_stats / onebit_rows_res_ln_rms / onebit_rows_swiglu_stats)" if tp_fused else "torch ops"}
+
+
+def measure_eval(model, dev, windows=8, seqlen=2048, requests=32):
+    """The reference's evaluation callers at their real shape on this model through the fused prefill
+    route: `perplexity` over `windows` windows of `seqlen` tokens (evaluation/lm_eval.py:93-128: one prefill per
+    window, fp16 logits, shifted cross-entropy) and `loglikelihood_tokens` over `requests` ragged requests of 40-400
+    tokens in one right-padded batch (evaluation/lm_eval/models_utils.py:275-330).  Synthetic token stream."""
+    from onebit_amd.evaluate import loglikelihood_tokens, perplexity
+    cfg = model.config
+    seqlen = min(seqlen, cfg.max_position_embeddings)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    stream = torch.randint(0, cfg.vocab_size, (1, windows * seqlen), generator=g)
+    lens = torch.randint(40, 401, (requests,), generator=g).tolist()
+    reqs = []
+    for n in lens:
+        toks = torch.randint(1, cfg.vocab_size, (n,), generator=g).tolist()
+        ncont = max(1, min(8, n // 8))
+        reqs.append((toks[:-ncont], toks[-ncont:]))
+    layer = model.model.layers[0]
+    projs = {"q/k/v/o": layer.self_attn.q_proj, "gate/up": layer.mlp.gate_proj, "down": layer.mlp.down_proj}
+
+    def routes(T):
+        return {k: ("LDS-DMA GEMM on producer-scaled rows" if p.prescaled_ok(T) else "register-staged MFMA GEMM") for k, p in projs.items()}
+    model.set_attention("hip").set_fused_glue(True)
+    try:
+        with torch.no_grad():
+            model(stream[:, :128].to(dev))                                           # warm-up (lazy initialisation)
+            perplexity(model, stream[:, :seqlen], seqlen, logits_dtype=torch.float16)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ppl = perplexity(model, stream, seqlen, logits_dtype=torch.float16)
+            torch.cuda.synchronize(dev)
+            dt_p = time.perf_counter() - t0
+            loglikelihood_tokens(model, reqs[:4], batch_size=requests, max_length=seqlen)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            res = loglikelihood_tokens(model, reqs, batch_size=requests, max_length=seqlen)
+            torch.cuda.synchronize(dev)
+            dt_l = time.perf_counter() - t0
+    finally:
+        model.set_attention("eager").set_fused_glue(False)
+        torch.cuda.empty_cache()
+    pad_to = max(len(c) + len(t) - 1 for c, t in reqs)
+    return {"perplexity": {"windows": windows, "seqlen": seqlen, "ms_per_window": round(dt_p / windows * 1e3, 2),
+                           "tokens_per_s": round(windows * seqlen / dt_p, 1), "ppl_synthetic": round(ppl, 1),
+                           "gemm_routes": routes(seqlen), "logits": "fp16 [1, %d, %d] per window, loss in fp16 (lm_eval.py:104-121)" % (seqlen, cfg.vocab_size)},
+            "loglikelihood_tokens": {"requests": requests, "lengths": "%d..%d tokens" % (min(lens), max(lens)), "padded_batch": [requests, pad_to],
+                                     "ms": round(dt_l * 1e3, 1), "tokens_per_s_padded": round(requests * pad_to / dt_l, 1),
+                                     "tokens_per_s_real": round(sum(len(c) + len(t) - 1 for c, t in reqs) / dt_l, 1),
+                                     "gemm_routes": routes(requests * pad_to), "finite": bool(all(v[0] == v[0] for v in res)),
+                                     "includes": "log_softmax over the vocabulary and the device->host copy of the [B, S, vocab] log-probabilities, as the reference does (models_utils.py:331)"},
+            "route": "set_fused_glue + onebit_attention_prefill (the config-3 prefill route)", "per": "GPU", "data": "synthetic"}
 
 
 def measure_cpu_baseline(cfg):
@@ -476,12 +601,56 @@ def measure_cpu_baseline(cfg):
     return out
 
 
-def main():
-    args = parse()
+class Hooks:
+    """Everything main() touches besides its own control flow (which ranks run what, where the collectives and
+    barriers sit, how the JSON line is assembled).  The world-2 gloo test (tests/test_bench_cpu.py) substitutes CPU
+    stand-ins, so the control flow the driver launches on N GPUs has executed with more than one rank."""
+    backend = "nccl"
+
+    def device(self, local_rank):
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        return dev
+
+    def init_process_group(self, dev):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, device_id=dev)
+
+    def sync(self, dev):
+        torch.cuda.synchronize(dev)
+
+    def empty_cache(self):
+        torch.cuda.empty_cache()
+
+    def load_lib(self):
+        from onebit_amd import _lib
+        _lib.load()
+
+    def build_model(self, cfg, seed, dev):
+        from onebit_amd.llama import build_synthetic_model
+        return build_synthetic_model(cfg, seed=seed, device=dev)
+
+    def make_stepper(self, model, max_len):
+        from onebit_amd.engine import DecodeEngine
+        return DecodeEngine(model, max_len=max_len)
+
+    measure_roofline = staticmethod(measure_roofline)
+    measure_prefill_sharded = staticmethod(measure_prefill_sharded)
+    measure_continuous_batch = staticmethod(measure_continuous_batch)
+    measure_prefill_model = staticmethod(measure_prefill_model)
+    measure_prefill_model_tp = staticmethod(measure_prefill_model_tp)
+    measure_k_sharded_decode = staticmethod(measure_k_sharded_decode)
+    measure_cpu_baseline = staticmethod(measure_cpu_baseline)
+    measure_eval = staticmethod(measure_eval)
+
+
+def main(argv=None, hooks=None):
+    args = parse(argv)
+    hk = hooks or Hooks()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain process: launch the N ranks ourselves (their rank 0 prints the JSON line)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:]), env=env))
+        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:] if argv is None else argv), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -489,19 +658,16 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE {world}; refusing to report a "
                          "rank count that was not measured")
     rccl_ranks = 1
+    dev = hk.device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        hk.init_process_group(dev)
         rccl_ranks = dist.get_world_size()
         assert rccl_ranks == args.gpus, (rccl_ranks, args.gpus)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
-    from onebit_amd import _lib
-    from onebit_amd.llama import build_synthetic_model
-    _lib.load()
+    hk.load_lib()
     cfg = model_config(args.model)
-    model = build_synthetic_model(cfg, seed=1000 * rank, device=dev)
+    model = hk.build_model(cfg, 1000 * rank, dev)
     g = torch.Generator(device="cpu").manual_seed(rank)
     prompt = torch.randint(0, cfg.vocab_size, (1, args.prompt), generator=g).to(dev)
     total_new = args.warmup + args.steps + 1
@@ -510,8 +676,7 @@ def main():
     stepper = None
     if engine in ("auto", "fused"):
         try:
-            from onebit_amd.engine import DecodeEngine
-            stepper = DecodeEngine(model, max_len=args.prompt + total_new + 1)
+            stepper = hk.make_stepper(model, args.prompt + total_new + 1)
             engine = "fused"
         except (ImportError, ValueError) as e:
             if engine == "fused":
@@ -531,10 +696,10 @@ def main():
         step = stepper.step
 
     def fence():
-        torch.cuda.synchronize(dev)
+        hk.sync(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            hk.sync(dev)
 
     for _ in range(args.warmup):
         step()
@@ -552,33 +717,39 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:      # right after the decode phase: same thermal / clock state as the headline
         ctx0 = args.prompt + args.warmup + args.steps // 2
-        roof = measure_roofline(model, dev, dt / args.steps * 1e3, token_bytes(cfg, ctx0)[1])
+        roof = hk.measure_roofline(model, dev, dt / args.steps * 1e3, token_bytes(cfg, ctx0)[1])
     prefill = None
     if not args.no_prefill:
         try:
-            prefill = measure_prefill_sharded(cfg, dev, world, rank)
+            prefill = hk.measure_prefill_sharded(cfg, dev, world, rank)
         except Exception as e:              # the decode line must survive a failure of the secondary measurement
             prefill = {"error": "%s: %s" % (type(e).__name__, e)}
     serve = None
     if not args.no_serve and rank == 0:
         try:
-            serve = measure_continuous_batch(model, dev)
+            serve = hk.measure_continuous_batch(model, dev)
         except Exception as e:
             serve = {"error": "%s: %s" % (type(e).__name__, e)}
     pmodel = None
     if not args.no_prefill and rank == 0:
         try:
-            pmodel = measure_prefill_model(model, dev)
+            pmodel = hk.measure_prefill_model(model, dev)
         except Exception as e:
             pmodel = {"error": "%s: %s" % (type(e).__name__, e)}
+    evalf = None
+    if not args.no_eval and rank == 0:          # the evaluation callers at their real shape
+        try:
+            evalf = hk.measure_eval(model, dev)
+        except Exception as e:
+            evalf = {"error": "%s: %s" % (type(e).__name__, e)}
     pmodel_tp = None
     if not args.no_prefill:
         try:
             if world > 1:                       # the same checkpoint on every rank (the decode replicas were seeded per rank)
                 del model
-                torch.cuda.empty_cache()
-                model = build_synthetic_model(cfg, seed=4242, device=dev)
-            pmodel_tp = measure_prefill_model_tp(model, dev, world, rank)
+                hk.empty_cache()
+                model = hk.build_model(cfg, 4242, dev)
+            pmodel_tp = hk.measure_prefill_model_tp(model, dev, world, rank)
         except Exception as e:
             pmodel_tp = {"error": "%s: %s" % (type(e).__name__, e)}
     ksd = None
@@ -586,8 +757,8 @@ def main():
         try:
             del stepper
             model = None
-            torch.cuda.empty_cache()
-            ksd = measure_k_sharded_decode(model_config("13b"), dev, world, rank, min(args.steps, 16), args.prompt)
+            hk.empty_cache()
+            ksd = hk.measure_k_sharded_decode(model_config("13b"), dev, world, rank, min(args.steps, 16), args.prompt)
             ksd["model"] = "LLaMA-13B shapes"
         except Exception as e:
             ksd = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -595,17 +766,17 @@ def main():
         # BASELINE config 5 names LLaMA2-13B: the same 32-slot steady-state step on a 13B-shaped synthetic checkpoint
         try:
             stepper = model = None
-            torch.cuda.empty_cache()
-            m13 = build_synthetic_model(model_config("13b"), seed=4242, device=dev)
-            serve["llama2_13b_shapes"] = measure_continuous_batch(m13, dev)
+            hk.empty_cache()
+            m13 = hk.build_model(model_config("13b"), 4242, dev)
+            serve["llama2_13b_shapes"] = hk.measure_continuous_batch(m13, dev)
             del m13
-            torch.cuda.empty_cache()
+            hk.empty_cache()
         except Exception as e:
             serve["llama2_13b_shapes"] = {"error": "%s: %s" % (type(e).__name__, e)}
     cpu = None
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            cpu = measure_cpu_baseline(cfg)
+        if not args.no_cpu_baseline:            # at every N (rank 0's host cores; the other ranks wait at the barrier below)
+            cpu = hk.measure_cpu_baseline(cfg)
     if world > 1:
         dist.barrier()
 
@@ -637,6 +808,8 @@ def main():
             out["prefill_model"] = pmodel
         if pmodel_tp is not None:
             out["prefill_model_tp"] = pmodel_tp
+        if evalf is not None:
+            out["eval_ppl"] = evalf
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

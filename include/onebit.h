@@ -247,6 +247,10 @@ typedef struct onebit_decode_state {
      * its workgroups.  fp32 [onebit_decode_stats_floats(model)], caller-owned, never read before
      * it is written (no initialisation needed).                                                  */
     float *tile_stats;
+    /* ABI 7, optional: fp16 [2 * head_dim] scratch.  With it the first launch of a step copies the rotary rows
+     * cos[pos], sin[pos] there and the 32 attention launches read THAT instead of chasing pos -> cos / sin
+     * themselves (one dependent memory round trip less on every layer's critical path).  NULL: as before.    */
+    void *rope_cur;
 } onebit_decode_state_t;
 
 size_t onebit_attn_scratch_bytes(const onebit_model_t *model, int32_t splits);

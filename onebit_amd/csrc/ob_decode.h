@@ -21,6 +21,7 @@
 // packed words as the A operand.  All weight loads of a wave are issued before the prologue so the
 // HBM latency overlaps the statistics; partial sums meet in LDS.
 #pragma once
+#include <type_traits>
 #include "ob_common.h"
 
 #ifndef OB_DEC_THREADS
@@ -62,6 +63,14 @@ struct ObGemvArgs {
     // workgroup barrier.  Buffers hold a multiple of 256 tiles (reads beyond K/16 are masked).
     const float *st_prev, *st_gate, *st_up;
     float rms_eps, ln_eps;
+    // WGP kernels (one projection per workgroup): workgroups [wg_end[p-1], wg_end[p]) own the tiles of projection p
+    int wg_end[3];
+    // EMBED_RMS (first launch of a step), optional: workgroup 0 copies the rotary rows of the current position,
+    // cos[pos] | sin[pos], to rope_out [2 * rope_D] for the step's attention launches (ObAttnArgs.rope_cur)
+    const int *rope_pos;
+    const _Float16 *rope_cos, *rope_sin;
+    _Float16 *rope_out;
+    int rope_D, rope_max;
     int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
     unsigned long long *dbg;       // profiling builds only: per-workgroup phase timestamps [grid][8]
 };
@@ -309,7 +318,11 @@ __device__ __forceinline__ ob_u32x4 ob_dec_load_w(const uint32_t *w, int N, int 
 #endif
         if (OB_DEC_W_NT) w4 = __builtin_nontemporal_load(reinterpret_cast<const ob_u32x4 *>(rowp + wc));
         else w4 = *reinterpret_cast<const ob_u32x4 *>(rowp + wc);
-        if (word >= nwords) w4 = (ob_u32x4){0u, 0u, 0u, 0u};
+        // words beyond the row (word >= nwords: the tail of the last chunk, chunks beyond K) are NOT zeroed: they re-read
+        // valid words (clamped address) and multiply activations that are zero there (the LDS images are zero-padded), so
+        // their value never matters -- and a select on the loaded registers right here is a USE at the issue point: in a
+        // straight-line phase it put s_waitcnt vmcnt(0) behind every rolling load (round 4)
+        (void)nwords;
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -383,14 +396,23 @@ __device__ __forceinline__ void ob_st8(_Float16 *p, const ob_half8 v)
 // dynamic LDS: activations (fp16: 2 B/k, i8: 4 digit bytes/k) per projection | cross-wave partials |
 //              reduction slots (256 floats)
 // ---------------------------------------------------------------------------------------------
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST>
+// WGP (round 4; NPROJ == 1 in the template, A.nproj projections in the launch): ONE PROJECTION PER WORKGROUP.  The
+// workgroups of a q|k|v or gate|up launch are dealt to the projections (A.wg_end) and a workgroup's MS slots are all
+// tiles of ITS projection.  The per-slot form above gave every workgroup one tile of every projection, so every
+// workgroup quantised x * h_p for every p (q|k|v: three amax + digit passes, 359 of 1129 instructions per wave) and
+// read every projection's digit planes from LDS for ONE use each (a B operand of v_mfma_i32_16x16x64_i8 is 1 KB per
+// wave and step; at 128 B/clk the q|k|v launch spent ~1500 cycles per workgroup on those reads: the gap between
+// "digits in LDS" and "first MFMA" in tools/phase_probe.py).  With one projection per workgroup the prologue quantises
+// once and each B operand feeds MS MFMAs.
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
+    static_assert(!WGP || NPROJ == 1, "WGP kernels are instantiated with NPROJ = 1");
     constexpr int MT = MS * NPROJ;
     // digit sums from the matrix pipe where several projections share the launch (gate|up, q|k|v: measured 7.16 -> 6.66 us
     // and 6.57 -> 6.6 us per launch); a single-projection launch with KV = 3 chunks per wave (down) would double its MFMA
     // count for the same saving and measured slower (7.22 -> 7.50 us): it keeps v_dot4 + DPP
-    constexpr bool SMF = OB_SMFMA && NPROJ >= 2;
+    constexpr bool SMF = OB_SMFMA && (NPROJ >= 2 || (WGP && MS >= 3));
     // PST: LayerNorm statistics of the prologue inputs come from the producers' per-tile partials
 #ifdef OB_STRIDED_LOADS                     // A/B switch (tools/phase_probe.py): 4-byte strided prologue loads, no transpose
     constexpr bool SD = MATH == 1;
@@ -399,7 +421,16 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                                             // load per lane); the integer path transposes inside quads later
 #endif
     // the projection descriptors live in SGPRs; selection by slot is compile-time
-    const ObProj PP[3] = {A.p[0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
+    int wg_local = (int)blockIdx.x, wg_count = (int)gridDim.x;
+    int pw = 0;
+    if (WGP) {
+        const int b = (int)blockIdx.x;
+        pw = (b >= A.wg_end[0] ? 1 : 0) + (b >= A.wg_end[1] ? 1 : 0);
+        const int b0 = pw == 0 ? 0 : (pw == 1 ? A.wg_end[0] : A.wg_end[1]);
+        wg_count = (pw == 0 ? A.wg_end[0] : (pw == 1 ? A.wg_end[1] : A.wg_end[2])) - b0;
+        wg_local = b - b0;
+    }
+    const ObProj PP[3] = {A.p[WGP ? pw : 0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;              // launch floor
@@ -419,13 +450,16 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     const int Kpad = (K + 511) & ~511;
     _Float16 *lds_a = reinterpret_cast<_Float16 *>(smem);
     char *lds_q = smem;
-    float *lds_red = reinterpret_cast<float *>(smem + (size_t)NPROJ * Kpad * (MATH == 1 ? 4 : 2));
+    // integer path: the digit image covers ALL KV * 8 chunks of a wave row (chunks beyond K hold zero digits, written by the
+    // wave that would own them), so the MFMA phase is one straight-line block with no per-chunk guard
+    constexpr int KQ = KV * OB_DEC_WAVES * 512;
+    float *lds_red = reinterpret_cast<float *>(smem + (MATH == 1 ? (size_t)NPROJ * KQ * 4 : (size_t)NPROJ * Kpad * 2));
     // i8: lds_red holds [MT][8 waves][16 rows][4 digits] scaled fp32 partials
     constexpr int RED_OFF = MATH == 1 ? (MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) : MT * OB_DEC_WAVES * 16;
     float *red = lds_red + RED_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gq = lane >> 4;
-    const int G = gridDim.x;
+    const int G = wg_count;
     const int nchunks = Kpad >> 9;
     const int per_tile = (nchunks - wave + OB_DEC_WAVES - 1) / OB_DEC_WAVES;   // this wave's chunks per tile
 
@@ -434,7 +468,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     bool tval[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int ti = (j / NPROJ) * G + (int)blockIdx.x;
+        const int ti = (j / NPROJ) * G + wg_local;
         const int ntile = (PP[j % NPROJ].N + 15) >> 4;
         tval[j] = ti < ntile;
         trow[j] = (tval[j] ? ti : 0) << 4;
@@ -530,6 +564,12 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #endif
 #ifndef OB_ISSUE_WIN
 #define OB_ISSUE_WIN 2
+#endif
+#ifdef OB_HEAD_BARRIER
+    // A/B (round 4): every wave's prologue-vector requests enter the CU's memory pipeline before any wave's weight
+    // stream (the vector L1 returns in request order: a late wave's 1 KB vector slices otherwise queue behind the
+    // early waves' HBM misses, and the RMSNorm barrier then waits for that wave)
+    __builtin_amdgcn_s_barrier();
 #endif
     ob_u32x4 wreg[MT][KV];
     constexpr int NITEM = MT * KV, NG = MS * KV;
@@ -770,7 +810,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             inv_scale[p] = __uint_as_float((uint32_t)(e - 29 + 127) << 23);               // 2^-(22-e+7)
             const float sc0 = scale * cj0, sc1 = scale * cj1;
             int D[4] = {0, 0, 0, 0};
-            char *dst = lds_q + (size_t)p * Kpad * 4 + (lane >> 2) * 128 + jp * 8;
+            char *dst = lds_q + (size_t)p * KQ * 4 + (lane >> 2) * 128 + jp * 8;
 #pragma unroll
             for (int v = 0; v < KV; ++v) {
                 uint32_t T[2][4];
@@ -798,11 +838,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                         for (int c = 0; c < 4; ++c) D[c] = __builtin_amdgcn_sdot4((int)T[s2][c], s2 ? vj1 : vj0, D[c], false);
                     }
                 }
-                if ((v * OB_DEC_WAVES + wave) * 512 < Kpad) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        *reinterpret_cast<ob_u32x2 *>(dst + (size_t)(v * OB_DEC_WAVES + wave) * 2048 + c * 32) = (ob_u32x2){T[0][c], T[1][c]};
-                }
+                for (int c = 0; c < 4; ++c)         // (a chunk beyond K: xh is zero there, so are its digits)
+                    *reinterpret_cast<ob_u32x2 *>(dst + (size_t)(v * OB_DEC_WAVES + wave) * 2048 + c * 32) = (ob_u32x2){T[0][c], T[1][c]};
             }
             // S of this wave, exact, digit (lane & 3) in every lane.  OB_SMFMA (default): S comes out of the matrix
             // pipe itself -- eight more MFMAs per chunk and projection whose A operand is the all-ones word's masks
@@ -856,61 +894,88 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         for (int p = 0; p < NPROJ; ++p) acc_s[p] = (ob_i32x4){0, 0, 0, 0};
         const ob_i32x4 ones_lo = {0x01010101, 0x02020202, 0x04040404, 0x08080808};
         const ob_i32x4 ones_hi = {0x10101010, 0x20202020, 0x40404040, (int)0x80808080u};
+        // IL accumulators are interleaved per MFMA step: the projections of a slot (per-slot form) or two slots of the
+        // workgroup's projection sharing ONE B operand (WGP) -- consecutive MFMAs never chain on one accumulator.
+        constexpr int IL = WGP ? (MS >= 2 ? 2 : 1) : NPROJ;
+        constexpr int NGRP = WGP ? ((MS + IL - 1) / IL) * KV : NG;
+        // (No per-chunk guard: a wave row's chunks beyond K multiply zero digits -- the guard made every group its own basic
+        //  block, the accumulators travelled through phi copies at the merges, and with two guarded copies of the phase the
+        //  waitcnt pass fell back to ONE vmcnt(0) in front of the first MFMA: the whole weight stream had to land first.)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int g = 0; g < NGRP; ++g) {
+            const int s = g / KV, ci = g % KV;          // s: slot (per-slot form) or slot pair (WGP)
             {
-                const int prev = g == 0 ? C4 : ((g * NPROJ + OB_ISSUE_WIN) > C4 ? (g * NPROJ + OB_ISSUE_WIN) : C4);
-                const int want = ((g + 1) * NPROJ + OB_ISSUE_WIN) > C4 ? ((g + 1) * NPROJ + OB_ISSUE_WIN) : C4;
-                if (prev < NITEM) OB_ISSUE(prev < NITEM ? prev : NITEM, want < NITEM ? want : NITEM);
+                // items consumed up to and including group g (WGP: all chunks of the slot pair at once)
+                const int need_prev = g == 0 ? 0 : (WGP ? ((g - 1) / KV + 1) * IL * KV : g * NPROJ);
+                const int need = WGP ? (s + 1) * IL * KV : (g + 1) * NPROJ;
+                const int prev = g == 0 ? C4 : ((need_prev + OB_ISSUE_WIN) > C4 ? (need_prev + OB_ISSUE_WIN) : C4);
+                const int want = (need + OB_ISSUE_WIN) > C4 ? (need + OB_ISSUE_WIN) : C4;
+                if (prev < NITEM && want > prev) OB_ISSUE(prev < NITEM ? prev : NITEM, want < NITEM ? want : NITEM);
             }
-            const int s = g / KV, ci = g % KV;
-            if (ci < per_tile) {
+            {
                 const int ch = wave + ci * OB_DEC_WAVES;
+                constexpr int NB = WGP ? 1 : NPROJ;      // distinct B operands per step
                 if (OB_BCACHE && (KV > 1 || s == 0)) {
 #pragma unroll
-                    for (int p = 0; p < NPROJ; ++p)
+                    for (int p = 0; p < NB; ++p)
 #pragma unroll
                         for (int qj = 0; qj < 8; ++qj)
-                            bc[p][qj] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + (qj >> 1) * 128 + (qj & 1) * 16);
+                            bc[p][qj] = *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * KQ * 4 + (size_t)ch * 2048 + (qj >> 1) * 128 + (qj & 1) * 16);
+                    __builtin_amdgcn_sched_barrier(0);          // the reads stay one burst (hipcc otherwise sinks each next to its MFMA)
                 }
+                // lane l of the step: slot jl(l), B operand bl(l); WGP: the last pair of an odd MS has one lane
+                auto jl = [&](int l) { return WGP ? s * IL + l : s * NPROJ + l; };
+                const int nl = WGP ? ((s + 1) * IL <= MS ? IL : MS - s * IL) : NPROJ;
+                const bool smf_here = SMF && s == 0;
                 // steps t = (q, jh) of the chunk, software-pipelined by one: the A operands (w & mask, 4 v_and per MFMA) of
                 // step t + 1 are formed BEFORE the MFMAs of step t are issued, in a second register set -- a v_and
                 // result feeding the very next instruction costs MFMA-hazard wait states and chains every MFMA behind
                 // its own operand preparation (hipcc reused ONE register quad for all 48 operands: 35 s_nop per wave)
-                auto masks = [&](int t, int p) -> ob_i32x4 {
-                    const uint32_t w = wreg[s * NPROJ + p][ci][t >> 1];
+                auto masks = [&](int t, int l) -> ob_i32x4 {
+                    const uint32_t w = wreg[jl(l)][ci][t >> 1];
                     ob_i32x4 av;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) av[v] = (int)(w & (0x01010101u << (4 * (t & 1) + v)));
                     return av;
                 };
-                ob_i32x4 avn[NPROJ];
+                ob_i32x4 avn[IL];
 #pragma unroll
-                for (int p = 0; p < NPROJ; ++p) avn[p] = masks(0, p);
+                for (int l = 0; l < IL; ++l) if (l < nl) avn[l] = masks(0, l);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    ob_i32x4 avc[NPROJ], bv[NPROJ];
+                    ob_i32x4 avc[IL], bv[NB];
 #pragma unroll
-                    for (int p = 0; p < NPROJ; ++p) {
-                        avc[p] = avn[p];
+                    for (int l = 0; l < IL; ++l) if (l < nl) avc[l] = avn[l];
+#pragma unroll
+                    for (int p = 0; p < NB; ++p)
                         bv[p] = OB_BCACHE ? bc[p][t]
-                                          : *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * Kpad * 4 + (size_t)ch * 2048 + (t >> 1) * 128 + (t & 1) * 16);
-                    }
+                                          : *reinterpret_cast<const ob_i32x4 *>(bq + (size_t)p * KQ * 4 + (size_t)ch * 2048 + (t >> 1) * 128 + (t & 1) * 16);
                     if (t < 7) {
 #pragma unroll
-                        for (int p = 0; p < NPROJ; ++p) avn[p] = masks(t + 1, p);
+                        for (int l = 0; l < IL; ++l) if (l < nl) avn[l] = masks(t + 1, l);
                     }
 #pragma unroll
-                    for (int p = 0; p < NPROJ; ++p) {
-                        const int j = s * NPROJ + p;
-                        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[p], bv[p], acc[j], 0, 0, 0);
-                        if (SMF && s == 0)                  // 128 * S of this chunk: the all-ones word through the same step
-                            acc_s[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8((t & 1) ? ones_hi : ones_lo, bv[p], acc_s[p], 0, 0, 0);
+                    for (int l = 0; l < IL; ++l) {
+                        if (l < nl) {
+                            const int j = jl(l);
+                            acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[l], bv[WGP ? 0 : l], acc[j], 0, 0, 0);
+                            if (smf_here && (!WGP || l == 0))  // 128 * S of this chunk: the all-ones word through the same step
+                                acc_s[WGP ? 0 : l] = __builtin_amdgcn_mfma_i32_16x16x64_i8((t & 1) ? ones_hi : ones_lo, bv[WGP ? 0 : l], acc_s[WGP ? 0 : l], 0, 0, 0);
+                        }
                     }
 #if OB_BCACHE
-                    if (t < 7) __builtin_amdgcn_sched_group_barrier(0x002, 4 * NPROJ, 0);                     // VALU: next step's masks
-                    if (SMF && s == 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPROJ, 0);         // MFMA: this step
-                    else __builtin_amdgcn_sched_group_barrier(0x008, NPROJ, 0);
+                    // (the builtin wants literal counts: nl and the MFMA count are constants only after unrolling)
+                    const int nm = nl + (smf_here ? (WGP ? 1 : nl) : 0);
+                    if (t < 7) {                                                                            // VALU: next step's masks
+                        if (nl == 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        else if (nl == 2) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                    }
+                    if (nm == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // MFMA: this step
+                    else if (nm == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    else if (nm == 3) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    else if (nm == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #endif
 #ifdef OB_PROFILE_STAMPS
                     if (g == 0 && t == 0) OB_STAMP(7);
@@ -970,6 +1035,13 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         }
         OB_STAMP(10);
     }
+    if (PRO == OB_P_EMBED_RMS) {
+        if (blockIdx.x == 0 && A.rope_out && tid < 2 * A.rope_D) {
+            const int ps = min(max(*A.rope_pos, 0), A.rope_max - 1);
+            const int d = tid < A.rope_D ? tid : tid - A.rope_D;
+            A.rope_out[tid] = (tid < A.rope_D ? A.rope_cos : A.rope_sin)[(int64_t)ps * A.rope_D + d];
+        }
+    }
     OB_STAMP_FLUSH();
 #undef OB_STAMP
 #undef OB_STAMP_FLUSH
@@ -990,6 +1062,7 @@ struct ObAttnArgs {
     float ln_eps;
     long long slot_stride;               // elements between the caches of consecutive slots (blockIdx.y); rows of
                                          // u_q / u_k / u_v / out are consecutive per slot
+    const _Float16 *rope_cur;            // optional [2 * D]: cos[pos] | sin[pos] copied by the step's first launch (no pos -> table chase here)
     const _Float16 *h_next;              // optional [H * D]: out <- fp16(out * h_next), o_proj's input scaling (bitnet.py:113)
                                          // for a consumer that takes pre-scaled rows (batched step, ob_skinny3.h)
 };
@@ -1084,6 +1157,8 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
     const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
     const _Float16 hnx = A.h_next ? A.h_next[head * D + dq] : (_Float16)1;
+    _Float16 cosh_ = (_Float16)0, sinh_ = (_Float16)0;
+    if (A.rope_cur) { cosh_ = A.rope_cur[dq]; sinh_ = A.rope_cur[D + dq]; }      // requested with everything else (uniform branch)
     int pos_early = 0;
     if (!BLIND) {
         pos_early = *A.pos;
@@ -1103,7 +1178,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
     if (pos < 0 || pos >= A.max_len) return;      // idle slot, or a step past the cache (host error: never write or
                                                   // read beyond the allocation); uniform, before any barrier
     const int L = pos + 1;
-    const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
+    if (!A.rope_cur) { cosh_ = A.cos[(int64_t)pos * D + dq]; sinh_ = A.sin[(int64_t)pos * D + dq]; }
     __builtin_amdgcn_sched_barrier(0);
 
     // LayerNorm statistics of the three rows: from the producer's tile partials (every wave, no

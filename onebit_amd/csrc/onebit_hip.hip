@@ -575,12 +575,12 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false>
 static void ob_launch_dec_gemv_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
     static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST>, attr_set, 160 * 1024);
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP>, attr_set, 160 * 1024);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
 }
 
 // PST (statistics from the producers' tile partials) exists for the prologues that normalise an
@@ -682,6 +682,32 @@ static ObPfPlan ob_dec_gemv_plan(const ObGemvArgs &a)
     return P;
 }
 
+// One projection per workgroup (ob_decode.h, WGP): the smallest slot count MS <= 8 for which the projections' workgroups
+// (ceil(tiles_p / MS) each) fit one round of CUs.  7B: q|k|v 3 x 64 workgroups of 4 tiles, gate|up 2 x 115 of 6;
+// 13B: 3 x 80 of 4, 2 x 124 of 7.
+static bool ob_dec_wgp_geometry(const ObGemvArgs &a, int &MS, int (&wg_end)[3])
+{
+    for (MS = 1; MS <= 8; ++MS) {
+        int tot = 0;
+        for (int p = 0; p < 3; ++p) {
+            if (p < a.nproj) tot += ((a.p[p].N + 15) / 16 + MS - 1) / MS;
+            wg_end[p] = tot;
+        }
+        if (tot <= ob_cu_count()) return true;
+    }
+    return false;
+}
+
+template <int KV, int MS>
+static bool ob_launch_dec_gemv_wgp(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
+{
+    if (a.prologue == OB_P_RES_LN_RMS && a.st_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true>(a, G, lds, s);
+    else if (a.prologue == OB_P_RES_LN_RMS) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, false, true>(a, G, lds, s);
+    else if (a.prologue == OB_P_EMBED_RMS) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_EMBED_RMS, 1, 1, false, true>(a, G, lds, s);
+    else return false;
+    return true;
+}
+
 static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 {
     ObGemvArgs a = a_in;
@@ -693,10 +719,27 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     bool aligned;
     ob_dec_gemv_geometry(a, max_tiles, KV, aligned, G, MS);
     const int Kpad = (a.K + 511) & ~511;
+    // launches of several projections: one projection per workgroup (OB_DEC_WGP=0: the per-slot form, A/B)
+    static const int wgp_env = getenv("OB_DEC_WGP") ? atoi(getenv("OB_DEC_WGP")) : 1;
+    if (wgp_env && a.nproj >= 2 && aligned && ob_decode_math() == 1 && KV <= 2 &&
+        (a.prologue == OB_P_RES_LN_RMS || a.prologue == OB_P_EMBED_RMS)) {
+        int MSw;
+        if (ob_dec_wgp_geometry(a, MSw, a.wg_end)) {
+            const int Gw = a.wg_end[a.nproj - 1];
+            const size_t lds_w = (size_t)KV * OB_DEC_WAVES * 512 * 4 + ((size_t)MSw * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
+            bool hit = lds_w > 160 * 1024, ok = false;        // (cannot happen for K <= 8192; then the per-slot form below)
+#define OB_WCASE(P, M) if (!hit && KV == P && MSw == M) { hit = true; ok = ob_launch_dec_gemv_wgp<P, M>(a, Gw, lds_w, s); }
+            OB_WCASE(1, 1) OB_WCASE(1, 2) OB_WCASE(1, 3) OB_WCASE(1, 4) OB_WCASE(1, 5) OB_WCASE(1, 6) OB_WCASE(1, 7) OB_WCASE(1, 8)
+            OB_WCASE(2, 1) OB_WCASE(2, 2) OB_WCASE(2, 3) OB_WCASE(2, 4) OB_WCASE(2, 5) OB_WCASE(2, 6) OB_WCASE(2, 7) OB_WCASE(2, 8)
+#undef OB_WCASE
+            if (hit && ok) return ob_launch_status("decode gemv");
+        }
+    }
     if (!aligned && KV != 1)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
     const int MT = MS * a.nproj;
-    const size_t lds_i8 = (size_t)a.nproj * Kpad * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
+    // (integer path: the digit image covers all KV * 8 chunks of a wave row, ob_decode.h)
+    const size_t lds_i8 = (size_t)a.nproj * KV * OB_DEC_WAVES * 512 * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
     const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2);
     const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
@@ -1394,6 +1437,12 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         a.st_prev = ts_down;
         a.rms_w = (const _Float16 *)L.input_layernorm_w;
         a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
+        // single-launch attention only (the split-KV kernels read the position first anyway)
+        const bool rope_cur = st->rope_cur && !(st->attn_splits > 1 && st->attn_scratch);
+        if (l == 0 && rope_cur) {
+            a.rope_pos = st->pos; a.rope_cos = (const _Float16 *)m->rope_cos; a.rope_sin = (const _Float16 *)m->rope_sin;
+            a.rope_out = (_Float16 *)st->rope_cur; a.rope_D = D; a.rope_max = m->max_len;
+        }
         if ((rc = ob_launch_dec_gemv(a, s))) return rc;
         // K3's launch description first: the attention launch's idle CUs prefetch its packed rows
         ObGemvArgs o = {};
@@ -1408,6 +1457,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
         at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
+        if (rope_cur) at.rope_cur = (const _Float16 *)st->rope_cur;
         if (st->attn_splits > 1 && st->attn_scratch) {
             const int S = st->attn_splits;
             if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);

@@ -48,7 +48,7 @@ class _State(ctypes.Structure):
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp),
-                ("tile_stats", _vp)]
+                ("tile_stats", _vp), ("rope_cur", _vp)]
 
 
 class _BatchState(ctypes.Structure):
@@ -186,7 +186,9 @@ class DecodeEngine:
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
-                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None)
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None, None)
+        self._rope_cur = z(2 * D)
+        self._state.rope_cur = self._rope_cur.data_ptr()
         self.lib.onebit_decode_stats_floats.restype = ctypes.c_size_t
         self.lib.onebit_decode_stats_floats.argtypes = [ctypes.POINTER(_Model)]
         self._tile_stats = torch.zeros(max(int(self.lib.onebit_decode_stats_floats(ctypes.byref(self._model))), 1),

@@ -50,3 +50,143 @@ def test_rank_count_mismatch_is_refused():
 def test_csrc_sha_is_stable():
     import bench
     assert bench.csrc_sha() == bench.csrc_sha() and len(bench.csrc_sha()) == 16
+
+
+# ---- bench.main() end to end with TWO ranks (gloo, CPU stand-ins for the device work) ----------------------------------
+def _main_worker(rank, world, port, q):
+    import contextlib
+    import io
+    import json
+    import types
+
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    calls = []
+
+    def collective(tag):                      # a section every rank must enter: a mismatch would deadlock (test timeout)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        assert int(t.item()) == world, tag
+        calls.append(tag)
+
+    class Stepper:
+        def __init__(self):
+            self.n = 0
+
+        def prefill(self, prompt):
+            assert prompt.shape == (1, 16)
+
+        def step(self):
+            self.n += 1
+
+    class CpuHooks(bench.Hooks):
+        backend = "gloo"
+
+        def device(self, local_rank):
+            return torch.device("cpu")
+
+        def init_process_group(self, dev):
+            dist.init_process_group("gloo")
+
+        def sync(self, dev):
+            pass
+
+        def empty_cache(self):
+            pass
+
+        def load_lib(self):
+            pass
+
+        def build_model(self, cfg, seed, dev):
+            calls.append(("build", seed))
+            return types.SimpleNamespace(config=cfg)
+
+        def make_stepper(self, model, max_len):
+            self.stepper = Stepper()
+            return self.stepper
+
+        @staticmethod
+        def measure_roofline(model, dev, ms, tok_bytes):
+            assert dist.get_rank() == 0
+            return {"bound": "hbm", "frac": 0.1}
+
+        @staticmethod
+        def measure_prefill_sharded(cfg, dev, world_, rank_):
+            collective("prefill_sharded")
+            return {"k_shards": world_}
+
+        @staticmethod
+        def measure_continuous_batch(model, dev):
+            assert dist.get_rank() == 0
+            return {"slots": 32}
+
+        @staticmethod
+        def measure_prefill_model(model, dev):
+            assert dist.get_rank() == 0
+            return {"ms": 1.0}
+
+        @staticmethod
+        def measure_eval(model, dev):
+            assert dist.get_rank() == 0
+            return {"perplexity": {}}
+
+        @staticmethod
+        def measure_prefill_model_tp(model, dev, world_, rank_):
+            collective("prefill_model_tp")
+            return {"tp_degree": world_}
+
+        @staticmethod
+        def measure_k_sharded_decode(cfg, dev, world_, rank_, steps, prompt):
+            collective("k_sharded_decode")
+            assert cfg.hidden_size == 5120                      # config 4 runs on 13B shapes at every N
+            return {"k_shards": world_}
+
+        @staticmethod
+        def measure_cpu_baseline(cfg):
+            assert dist.get_rank() == 0
+            return {"value": 1.0, "unit": "tokens/s", "cores": 1, "kind": "port", "sample": "stand-in"}
+
+    hooks = CpuHooks()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--model", "tiny"], hooks=hooks)
+    assert hooks.stepper.n == 4                                 # warm-up + timed steps, every rank
+    assert [c for c in calls if isinstance(c, str)] == ["prefill_sharded", "prefill_model_tp", "k_sharded_decode"]
+    # replicas are seeded per rank; the tensor-parallel leg rebuilds the SAME checkpoint on every rank
+    assert ("build", 1000 * rank) in calls and ("build", 4242) in calls
+    out = buf.getvalue().strip()
+    if rank == 0:
+        q.put(json.loads(out.splitlines()[-1]))
+    else:
+        assert out == ""                                        # one JSON line per job, from rank 0 only
+
+
+def test_main_control_flow_two_ranks_gloo():
+    """bench.py's main() with --gpus 2 executed by two gloo ranks (device work replaced by stand-ins that keep the
+    collectives): which ranks run what, where the barriers sit, the JSON line -- in particular `cpu_baseline` is
+    present at N > 1 and config 4 / tensor-parallel prefill are entered by every rank."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    line = q.get(timeout=5)
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["metric"] == "decode_tokens_per_sec" and line["value"] > 0
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["kind"] == "port"        # emitted at every N
+    assert line["roofline"]["bound"] == "hbm"
+    for k in ("prefill_k_sharded", "decode_k_sharded", "continuous_batch", "prefill_model", "prefill_model_tp", "eval_ppl"):
+        assert k in line, k
+    assert line["decode_k_sharded"]["k_shards"] == 2 and line["decode_k_sharded"]["model"] == "LLaMA-13B shapes"

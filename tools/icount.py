@@ -10,10 +10,13 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                        "-DOB_PROFILE_STAMPS", *sys.argv[1:], "-S", "--cuda-device-only", "-o", out,
                        os.path.join(ROOT, "onebit_amd/csrc/onebit_hip.hip")], stderr=subprocess.DEVNULL)
 text = open(out).read().split("\n")
-kernels = {"gate|up": "_Z18ob_dec_gemv_kernelILi1ELi3ELb1ELi2ELi1ELi2ELb1EEv10ObGemvArgs",
-           "q|k|v": "_Z18ob_dec_gemv_kernelILi1ELi1ELb1ELi2ELi1ELi3ELb1EEv10ObGemvArgs",
-           "down": "_Z18ob_dec_gemv_kernelILi3ELi1ELb1ELi3ELi1ELi1ELb1EEv10ObGemvArgs",
-           "o": "_Z18ob_dec_gemv_kernelILi1ELi1ELb1ELi0ELi0ELi1ELb0EEv10ObGemvArgs"}
+# template arguments: KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP
+kernels = {"gate|up (WGP, MS 6)": "_Z18ob_dec_gemv_kernelILi1ELi6ELb1ELi2ELi1ELi1ELb1ELb1EEv10ObGemvArgs",
+           "q|k|v (WGP, MS 4)": "_Z18ob_dec_gemv_kernelILi1ELi4ELb1ELi2ELi1ELi1ELb1ELb1EEv10ObGemvArgs",
+           "gate|up (per-slot)": "_Z18ob_dec_gemv_kernelILi1ELi3ELb1ELi2ELi1ELi2ELb1ELb0EEv10ObGemvArgs",
+           "q|k|v (per-slot)": "_Z18ob_dec_gemv_kernelILi1ELi1ELb1ELi2ELi1ELi3ELb1ELb0EEv10ObGemvArgs",
+           "down": "_Z18ob_dec_gemv_kernelILi3ELi1ELb1ELi3ELi1ELi1ELb1ELb0EEv10ObGemvArgs",
+           "o": "_Z18ob_dec_gemv_kernelILi1ELi1ELb1ELi0ELi0ELi1ELb0ELb0EEv10ObGemvArgs"}
 names = ["kernarg", "head", "LN stats", "RMS", "x", "amax", "digits", "1st MFMA", "MFMA", "reduce", "finish", "flush"]
 for label, sym in kernels.items():
     try:
@@ -32,4 +35,4 @@ for label, sym in kernels.items():
         else: cur.append(t)
     seg.append(cur)
     tot = sum(len(x) for x in seg)
-    print("%-8s total %4d | " % (label, tot) + "  ".join("%s %d" % (names[i] if i < len(names) else "s%d" % i, len(x)) for i, x in enumerate(seg)))
+    print("%-20s total %4d | " % (label, tot) + "  ".join("%s %d" % (names[i] if i < len(names) else "s%d" % i, len(x)) for i, x in enumerate(seg)))
