@@ -199,6 +199,63 @@ __device__ __forceinline__ void ob_tiles_combine(const ObTileStats<NV> &r, int n
     rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
 }
 
+// Cooperative form for the long vectors of the SwiGLU prologue (two vectors of up to 16384 elements: 11 KB of pairs at
+// 7B -- read by each of the 8 waves that was 88 KB per workgroup through the vector L1, more than the vectors
+// themselves).  Each WAVE loads and combines 1/8 of the pairs (lanes 0 .. 8 NV - 1, one 4-tile slot each) and publishes
+// (elements, mean, M2) of its share; after ONE workgroup barrier every thread merges the 8 triples (Chan et al. again).
+struct ObTileSlot { ob_float4 a0, a1; };
+template <int NV>
+__device__ __forceinline__ void ob_tiles_slot_load(ObTileSlot &r, const float *st, int wave, int lane)
+{
+    const int q = wave * (8 * NV) + min(lane, 8 * NV - 1);
+    const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)q * 8);
+    r.a0 = p[0];
+    r.a1 = p[1];
+}
+template <int NV>
+__device__ __forceinline__ ob_float4 ob_tiles_slot_partial(const ObTileSlot &r, int n, int wave, int lane)
+{
+    const int ntiles = n >> 4;
+    const int t0 = (wave * (8 * NV) + lane) * 4;
+    const bool act = lane < 8 * NV;
+    const float sv[4] = {r.a0[0], r.a0[2], r.a1[0], r.a1[2]}, qv[4] = {r.a0[1], r.a0[3], r.a1[1], r.a1[3]};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (act && t0 + i < ntiles) ? sv[i] : 0.f;
+    s = ob_wave_sum(s);
+    const int tiles_w = min(max(ntiles - wave * (32 * NV), 0), 32 * NV);      // this wave's tiles that exist
+    const float n_w = 16.0f * (float)tiles_w;
+    const float mean_w = s * __builtin_amdgcn_rcpf(fmaxf(n_w, 1.0f));
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float d = __builtin_fmaf(sv[i], 0.0625f, -mean_w);
+        m2 += (act && t0 + i < ntiles) ? __builtin_fmaf(16.0f * d, d, qv[i]) : 0.f;
+    }
+    m2 = ob_wave_sum(m2);
+    return (ob_float4){n_w, mean_w, m2, 0.f};
+}
+// merge of the 8 per-wave triples at slot[w * 8 + 4 * vec .. + 3] (floats)
+template <int NW>
+__device__ __forceinline__ void ob_tiles_slot_merge(const float *slot, int vec, int n, float eps, float &mean, float &rstd)
+{
+    ob_float4 t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = *reinterpret_cast<const ob_float4 *>(slot + w * 8 + 4 * vec);
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) S = __builtin_fmaf(t[w][0], t[w][1], S);
+    const float inv_n = __builtin_amdgcn_rcpf((float)n);
+    mean = S * inv_n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float d = t[w][1] - mean;
+        m2 += __builtin_fmaf(t[w][0] * d, d, t[w][2]);
+    }
+    rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
+}
+
 // The same for a vector whose length is a runtime value (<= 16384): blocks of 256 tiles beyond
 // n / 16 are neither loaded nor counted.
 struct ObTileStatsRt { ob_float4 a[2]; };          // block 0 (the first 4096 elements); further blocks are re-read in the combine
@@ -430,7 +487,25 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
         wg_count = (pw == 0 ? A.wg_end[0] : (pw == 1 ? A.wg_end[1] : A.wg_end[2])) - b0;
         wg_local = b - b0;
     }
-    const ObProj PP[3] = {A.p[WGP ? pw : 0], A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
+    // every prologue argument is requested in the first scalar-load clause (hipcc fetches kernel arguments where they are
+    // first used: a second s_load / s_waitcnt round trip stood in front of the vector requests)
+    if (PRO == OB_P_RES_LN_RMS) asm volatile("" :: "s"(A.hres_in), "s"(A.u_prev), "s"(A.hres_out), "s"(A.rms_w), "s"(A.st_prev), "s"(A.K));
+    if (PRO == OB_P_EMBED_RMS) asm volatile("" :: "s"(A.embed), "s"(A.token), "s"(A.hres_out), "s"(A.rms_w), "s"(A.K));
+    if (PRO == OB_P_SWIGLU) asm volatile("" :: "s"(A.u_gate), "s"(A.u_up), "s"(A.st_gate), "s"(A.st_up), "s"(A.K));
+    if (PRO == OB_P_PLAIN) asm volatile("" :: "s"(A.xin), "s"(A.K));
+    // WGP: the workgroup's projection descriptor by uniform selects over all three (A.p[pw] as a dynamic index is a second,
+    // dependent scalar-load round trip at the head of every launch)
+    ObProj PW = A.p[0];
+    if (WGP) {
+        const ObProj &P1 = A.p[1], &P2 = A.p[2];
+        asm volatile("" :: "s"(PW.w), "s"(PW.h), "s"(PW.g), "s"(PW.u), "s"(PW.st), "s"(PW.N), "s"(PW.ldw),
+                     "s"(P1.w), "s"(P1.h), "s"(P1.g), "s"(P1.u), "s"(P1.st), "s"(P1.N), "s"(P1.ldw),
+                     "s"(P2.w), "s"(P2.h), "s"(P2.g), "s"(P2.u), "s"(P2.st), "s"(P2.N), "s"(P2.ldw));
+#define OB_PSEL(f) PW.f = pw == 0 ? PW.f : (pw == 1 ? P1.f : P2.f)
+        OB_PSEL(w); OB_PSEL(h); OB_PSEL(g); OB_PSEL(u); OB_PSEL(st); OB_PSEL(N); OB_PSEL(K); OB_PSEL(ldw);
+#undef OB_PSEL
+    }
+    const ObProj PP[3] = {PW, A.p[NPROJ > 1 ? 1 : 0], A.p[NPROJ > 2 ? 2 : 0]};
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef OB_PROFILE_ABLATE
     if (A.ablate == 4) return;              // launch floor
@@ -501,9 +576,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) hp[p][v] = ob_ld8<SD>(PP[p].h + vbase[v]);
     }
-    ObTileStats<KV> ts0, ts1;
+    ObTileStats<KV> ts0;
+    ObTileSlot tg, tu;
     if (PST) {
-        if (PRO == OB_P_SWIGLU) { ob_tiles_load<KV>(ts0, A.st_gate, lane); ob_tiles_load<KV>(ts1, A.st_up, lane); }
+        if (PRO == OB_P_SWIGLU) { ob_tiles_slot_load<KV>(tg, A.st_gate, wave, lane); ob_tiles_slot_load<KV>(tu, A.st_up, wave, lane); }
         if (PRO == OB_P_RES_LN_RMS) ob_tiles_load<KV>(ts0, A.st_prev, lane);
     } else {
         if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
@@ -565,15 +641,23 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #ifndef OB_ISSUE_WIN
 #define OB_ISSUE_WIN 2
 #endif
-#ifdef OB_HEAD_BARRIER
-    // A/B (round 4): every wave's prologue-vector requests enter the CU's memory pipeline before any wave's weight
-    // stream (the vector L1 returns in request order: a late wave's 1 KB vector slices otherwise queue behind the
-    // early waves' HBM misses, and the RMSNorm barrier then waits for that wave)
+#ifndef OB_HEAD_BARRIER
+#define OB_HEAD_BARRIER 1
+#endif
+#if OB_HEAD_BARRIER
+    // Round 4: every wave's prologue-vector requests enter the CU's memory pipeline before any wave's weight stream.
+    // Waves of a workgroup start hundreds of cycles apart and the vector L1 returns in request order: a late wave's
+    // 1 KB vector slices queued behind the early waves' HBM misses, and the first workgroup barrier then waited for that
+    // wave (tools/phase_probe.py: statistics ready 1700 median / 3700 max).  1055 -> 1085 tok/s; -DOB_HEAD_BARRIER=0: A/B.
     __builtin_amdgcn_s_barrier();
 #endif
     ob_u32x4 wreg[MT][KV];
     constexpr int NITEM = MT * KV, NG = MS * KV;
-    constexpr int C0 = NITEM < OB_ISSUE0 ? NITEM : OB_ISSUE0;
+#ifndef OB_ISSUE0_SWIGLU
+#define OB_ISSUE0_SWIGLU OB_ISSUE0
+#endif
+    constexpr int I0 = PRO == OB_P_SWIGLU ? OB_ISSUE0_SWIGLU : OB_ISSUE0;     // (A/B: fewer weight requests ahead of the long SwiGLU prologue)
+    constexpr int C0 = NITEM < I0 ? NITEM : I0;
     constexpr int C1 = NITEM < C0 + OB_ISSUE_STEP ? NITEM : C0 + OB_ISSUE_STEP;
     constexpr int C2 = NITEM < C1 + OB_ISSUE_STEP ? NITEM : C1 + OB_ISSUE_STEP;
     constexpr int C3 = NITEM < C2 + OB_ISSUE_STEP ? NITEM : C2 + OB_ISSUE_STEP;
@@ -605,9 +689,15 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     } else if (PRO == OB_P_SWIGLU) {
         float mg, rg, mu, ru;
         if (PST) {
-            ob_tiles_combine<KV>(ts0, K, A.ln_eps, lane, mg, rg);
-            ob_tiles_combine<KV>(ts1, K, A.ln_eps, lane, mu, ru);
+            const ob_float4 pg = ob_tiles_slot_partial<KV>(tg, K, wave, lane), pu = ob_tiles_slot_partial<KV>(tu, K, wave, lane);
+            if (lane == 0) {
+                *reinterpret_cast<ob_float4 *>(red + wave * 8) = pg;
+                *reinterpret_cast<ob_float4 *>(red + wave * 8 + 4) = pu;
+            }
+            __syncthreads();
             OB_ISSUE(C0, C1);
+            ob_tiles_slot_merge<OB_DEC_WAVES>(red, 0, K, A.ln_eps, mg, rg);
+            ob_tiles_slot_merge<OB_DEC_WAVES>(red, 1, K, A.ln_eps, mu, ru);
         } else {
             const float c0 = (float)c0h, c1 = (float)c1h;
             ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
@@ -1111,9 +1201,16 @@ __device__ __forceinline__ float ob_rows_max(float v)
 template <bool PST, int NTH, bool BLIND = true>
 __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in, const ObPfPlan PF)
 {
+    ObAttnArgs A = A_in;
+    if (BLIND) {
+        // every kernel argument is requested in ONE scalar-load clause (hipcc fetches fields where they are first used:
+        // four dependent s_load / s_waitcnt round trips stood between the kernel entry and the last vector request)
+        asm volatile("" :: "s"(A.u_q), "s"(A.u_k), "s"(A.u_v), "s"(A.cos), "s"(A.sin), "s"(A.kcache), "s"(A.vcache), "s"(A.out),
+                     "s"(A.pos), "s"(A.st_q), "s"(A.st_k), "s"(A.st_v), "s"(A.rope_cur), "s"(A.h_next), "s"(A.H), "s"(A.Hkv),
+                     "s"(A.D), "s"(A.max_len), "s"(A.ln_eps));
+    }
     if (BLIND && ob_prefetch_only_wg(PF, A_in.H, (int)threadIdx.x, NTH)) return;
     constexpr int NWV = NTH / 64, PG = NTH / 16, NI = 128 / PG;
-    ObAttnArgs A = A_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
     const int head = blockIdx.x, kvh = head / (H / Hkv);
@@ -1174,9 +1271,13 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             kreg[i] = (ob_half8)(_Float16)0; vreg[i] = (ob_half8)(_Float16)0;
         }
     }
-    const int pos = BLIND ? *A.pos : pos_early;
-    if (pos < 0 || pos >= A.max_len) return;      // idle slot, or a step past the cache (host error: never write or
-                                                  // read beyond the allocation); uniform, before any barrier
+    // BLIND: no early return on the position -- hipcc sinks every load that is only used behind such a branch BELOW it
+    // (the "blind" K / V requests were issued after the position had arrived: the dependent round trip they exist to
+    // avoid).  An invalid position (a step past the cache: host error) computes on position 0 and stores nothing.
+    const int pos_raw = BLIND ? *A.pos : pos_early;
+    const bool live = pos_raw >= 0 && pos_raw < A.max_len;
+    if (!BLIND && !live) return;                  // idle slot (batched step): uniform, before any barrier
+    const int pos = live ? pos_raw : 0;
     const int L = pos + 1;
     if (!A.rope_cur) { cosh_ = A.cos[(int64_t)pos * D + dq]; sinh_ = A.sin[(int64_t)pos * D + dq]; }
     __builtin_amdgcn_sched_barrier(0);
@@ -1216,7 +1317,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             const float qr = tid < half ? -q1 : q1, kr = tid < half ? -k1 : k1;
             qe = ob_round_h(ob_round_h(q0 * c) + ob_round_h(qr * sn));
             ke = ob_round_h(ob_round_h(k0 * c) + ob_round_h(kr * sn));
-            if (head % (H / Hkv) == 0) {      // one workgroup per kv head appends to the cache
+            if (live && head % (H / Hkv) == 0) {      // one workgroup per kv head appends to the cache
                 A.kcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ke;
                 A.vcache[((int64_t)kvh * A.max_len + pos) * D + tid] = (_Float16)ve;
             }
@@ -1351,7 +1452,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         for (int w = 0; w < NWV; ++w) acc += po[w * 128 + tid];
         _Float16 oh = (_Float16)acc;
         if (A.h_next) oh = oh * hnx;
-        A.out[head * D + tid] = oh;
+        if (live) A.out[head * D + tid] = oh;
     }
 }
 

@@ -158,8 +158,13 @@ __global__ __launch_bounds__(OB_TG_THREADS) void ob_tgemm_kernel(const ObTGemmAr
                 if (EPI == OB_TE_PLAIN) C[o] = c;
                 if (EPI == OB_TE_GX) { C[o] = c; C2[o] = (TI)(c * vc[n + e]); }
                 if (EPI == OB_TE_STE) {
-                    const float t = tanhf((float)vc[o]);
-                    C[o] = (TI)((float)c * (1.001f - t * t));
+                    // SignSTEFunc.backward (bitnet.py:22-23): grad * (1.001 - tanh(w) ** 2) as TENSOR ops in the tensor
+                    // dtype -- tanh, the square, the subtraction (the scalar 1.001 becomes TI: 1.000977 in fp16) and the
+                    // product each round once to TI
+                    const TI t = (TI)tanhf((float)vc[o]);
+                    const TI t2 = (TI)((float)t * (float)t);
+                    const TI f = (TI)((float)(TI)1.001f - (float)t2);
+                    C[o] = (TI)((float)c * (float)f);
                 }
             }
         }

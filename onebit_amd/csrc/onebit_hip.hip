@@ -655,9 +655,14 @@ static void ob_dec_gemv_geometry(const ObGemvArgs &a, int &max_tiles, int &KV, b
     for (int p = 0; p < a.nproj; ++p) aligned = aligned && (a.p[p].ldw % 4 == 0) && ob_aligned(a.p[p].w, 16);
     // slots per projection: instantiated 1 2 3 4 (KV = 1), 1 2 (KV = 2), 1 (KV = 4); the grid grows beyond
     // one workgroup per CU when a projection has more tiles than that
-    const int ms_max = KV == 1 ? 4 : (KV == 2 ? 2 : 1);      // KV 3, 4: one slot
+    // (A/B, round 4: OB_DEC_SWIGLU_WGS=128 runs down_proj as 128 workgroups of two tiles -- half the redundant reads of the
+    //  44-66 KB of prologue vectors through the L2s, each B operand used twice)
+    static const int sw_wgs = getenv("OB_DEC_SWIGLU_WGS") ? atoi(getenv("OB_DEC_SWIGLU_WGS")) : 0;
+    const bool sw2 = sw_wgs > 0 && a.nproj == 1 && a.prologue == OB_P_SWIGLU && KV >= 3;
+    const int ms_max = KV == 1 ? 4 : (KV == 2 || sw2 ? 2 : 1);      // KV 3, 4: one slot
     static const int wgs_per_cu = getenv("OB_DEC_WGS_PER_CU") ? atoi(getenv("OB_DEC_WGS_PER_CU")) : 1;   // A/B switch
     G = ob_cu_count() * (wgs_per_cu > 0 ? wgs_per_cu : 1);
+    if (sw2 && sw_wgs < G) G = sw_wgs;
     if (max_tiles < G) G = max_tiles;
     if ((max_tiles + G - 1) / G > ms_max) G = (max_tiles + ms_max - 1) / ms_max;
     MS = (max_tiles + G - 1) / G;
@@ -758,8 +763,8 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     }
     OB_CASE(1, 1) OB_CASE(1, 2) OB_CASE(1, 3) OB_CASE(1, 4)
     OB_CASE(2, 1) OB_CASE(2, 2)
-    OB_CASE(3, 1)
-    OB_CASE(4, 1)
+    OB_CASE(3, 1) OB_CASE(3, 2)
+    OB_CASE(4, 1) OB_CASE(4, 2)
     OB_CASE_U(1) OB_CASE_U(2) OB_CASE_U(3) OB_CASE_U(4)
 #undef OB_CASE
 #undef OB_CASE_U

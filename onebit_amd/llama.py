@@ -174,16 +174,17 @@ class LlamaAttentionInf(nn.Module):
         kc[:B, :, past_len:past_len + S] = k
         vc[:B, :, past_len:past_len + S] = v
         L = past_len + S
+        if self.attn_impl == "hip" and S > 1 and q.dtype == torch.float16 and D in (64, 128) and kc.is_contiguous() and vc.is_contiguous():
+            # the build's own fused causal attention (onebit_attention_prefill: flash style on MFMA, csrc/ob_flash.h),
+            # any past_len; q goes in token-major, the output comes back as the [B, S, H * D] rows o_proj consumes.
+            # (before the GQA expansion below: the kernel indexes the kv heads itself)
+            o = hip_attention_prefill(q.transpose(1, 2).contiguous(), kc, vc, past_len)
+            return o_proj(o.view(B, S, H * D))
         keys, vals = kc[:B, :, :L], vc[:B, :, :L]
         if Hkv != H:
             rep = H // Hkv
             keys = keys.repeat_interleave(rep, dim=1)
             vals = vals.repeat_interleave(rep, dim=1)
-        if self.attn_impl == "hip" and S > 1 and q.dtype == torch.float16 and D in (64, 128) and kc.is_contiguous() and vc.is_contiguous():
-            # the build's own fused causal attention (onebit_attention_prefill: flash style on MFMA, csrc/ob_flash.h),
-            # any past_len; q goes in token-major, the output comes back as the [B, S, H * D] rows o_proj consumes
-            o = hip_attention_prefill(q.transpose(1, 2).contiguous(), kc, vc, past_len)
-            return o_proj(o.view(B, S, H * D))
         if self.attn_impl == "sdpa" and S > 1 and past_len == 0:
             # fused causal attention (the reference offers the same switch: LlamaFlashAttention2 under
             # config._flash_attn_2_enabled, modeling_bitllama.py:588,862): no [S, S] score tensor in HBM.

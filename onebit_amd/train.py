@@ -19,6 +19,7 @@ from __future__ import annotations
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch import nn
 
 from . import _lib
@@ -56,6 +57,7 @@ class _BitLinearFn(torch.autograd.Function):
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
+    @once_differentiable               # the gradients come out of a C-ABI call: no graph behind them, no double backward
     def backward(ctx, gy):
         x2, w, g, h, z, stats = ctx.saved_tensors
         N, K = w.shape
@@ -76,7 +78,10 @@ class _BitLinearFn(torch.autograd.Function):
                                            None if gb is None else gb.data_ptr(), ws.data_ptr(), nws, T, K, N, ctx.code,
                                            _stream_ptr(dev))
         _lib.check(rc, "onebit_train_backward")
-        return gx.view(*ctx.lead, K), gw, gg, gh, gb, None
+        # (one fused call computes all five; outputs autograd did not ask for are dropped, not returned as garbage)
+        need = ctx.needs_input_grad
+        return (gx.view(*ctx.lead, K) if need[0] else None, gw if need[1] else None, gg if need[2] else None,
+                gh if need[3] else None, gb if (gb is not None and need[4]) else None, None)
 
 
 def bitlinear_train(x, weight, weight_scale, input_factor, bias=None, eps: float = 1e-5):
