@@ -555,6 +555,17 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     int vbase[KV];
     ob_half8 v0[KV], v1[KV], v2[KV], hp[NPROJ][KV];
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
+    // the LayerNorm partials first (requests return in order and the statistics are what the prologue needs first), the
+    // consumers' input_factor rows last (needed after the whole elementwise chain)
+    ObTileStats<KV> ts0;
+    ObTileSlot tg, tu;
+    if (PST) {
+        if (PRO == OB_P_SWIGLU) { ob_tiles_slot_load<KV>(tg, A.st_gate, wave, lane); ob_tiles_slot_load<KV>(tu, A.st_up, wave, lane); }
+        if (PRO == OB_P_RES_LN_RMS) ob_tiles_load<KV>(ts0, A.st_prev, lane);
+    } else {
+        if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
+        if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
+    }
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
         const int base = SD ? (v * OB_DEC_WAVES + wave) * 512 + (lane >> 2) * 32 + (lane & 3) * 2
@@ -573,17 +584,11 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             }
             v2[v] = ob_ld8<SD>(A.rms_w + vbase[v]);
         }
+    }
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
 #pragma unroll
         for (int p = 0; p < NPROJ; ++p) hp[p][v] = ob_ld8<SD>(PP[p].h + vbase[v]);
-    }
-    ObTileStats<KV> ts0;
-    ObTileSlot tg, tu;
-    if (PST) {
-        if (PRO == OB_P_SWIGLU) { ob_tiles_slot_load<KV>(tg, A.st_gate, wave, lane); ob_tiles_slot_load<KV>(tu, A.st_up, wave, lane); }
-        if (PRO == OB_P_RES_LN_RMS) ob_tiles_load<KV>(ts0, A.st_prev, lane);
-    } else {
-        if (PRO == OB_P_SWIGLU) { c0h = A.u_gate[0]; c1h = A.u_up[0]; }
-        if (PRO == OB_P_RES_LN_RMS) c0h = A.u_prev[0];
     }
     // 1b. embedding row: the one dependent load (token id first), once per token
     if (PRO == OB_P_EMBED_RMS) {
@@ -1348,7 +1353,8 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         const int p = pg + PG * i;
         sreg[i] = -INFINITY;
         // (batched step: whole sweeps beyond the sequence are skipped -- uniform per workgroup; with heads x slots
-        // workgroups sharing the SIMDs every masked instruction is somebody else's issue slot)
+        // workgroups sharing the SIMDs every masked instruction is somebody else's issue slot.  The single-sequence kernel
+        // computes all eight sweeps: skipping them by uniform branches measured SLOWER, 5.0 -> 5.5 us per launch, round 4)
         if (BLIND || PG * i < L) {
             const float dot = ob_row_sum(dot8(q8, p == pos ? kn8 : kreg[i]));
             const float sv = ob_round_h(ob_round_h(dot) * inv_sqrt_d);

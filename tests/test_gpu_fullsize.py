@@ -192,6 +192,34 @@ def test_native_batched_step_32_slots_13b_layers():
             assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
 
 
+@pytest.mark.parametrize("slots", [40, 64])
+def test_native_batched_step_13b_layers_beyond_32_slots(slots):
+    """33 .. 64 slots select the 64-token tile of the LDS-DMA skinny GEMM; at 13B widths its gate | up launch needs 8 row
+    tiles per workgroup (2 x 108 workgroups) -- the instance that did not exist in round 3, so that the step failed with
+    'no skinny GEMM instance' (ADVICE round 3, high).  Every slot's greedy tokens against single-sequence generate."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.serving import ContinuousBatcher
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=1024, hidden_size=5120, intermediate_size=13824, num_hidden_layers=1,
+                            num_attention_heads=40, max_position_embeddings=64)
+    model = build_synthetic_model(cfg, seed=14, device=dev)
+    g = torch.Generator().manual_seed(5)
+    reqs = [(torch.randint(0, cfg.vocab_size, (int(n),), generator=g).tolist(), 4) for n in torch.randint(2, 12, (slots,), generator=g)]
+    cb = ContinuousBatcher(model, max_batch=slots, max_len=32)
+    assert cb._native is not None
+    rids = [cb.add_request(p, m) for p, m in reqs]
+    out = cb.run()
+    assert cb.graph_steps > 0
+    for rid, (p, m) in zip(rids, reqs):
+        ref = model.generate(torch.tensor([p], device=dev), m)[0, len(p):].tolist()
+        got = out[rid]
+        assert len(got) == m
+        if got != ref:
+            j = next(i for i in range(m) if got[i] != ref[i])
+            lg = model(torch.tensor([p + ref[:j]], device=dev))[0, -1]
+            assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (rid, j)
+
+
 def test_k_sharded_prefill_full_size_vs_oracle(coracle):
     """The K-sharded form of config 3 at full size (T = 16384, 4096 -> 11008 as two K slices of 2048 passed
     in place): onebit_matmul_partial_ws with room for the pre-scaled slice (the LDS-DMA GEMM in its fp32
