@@ -154,7 +154,7 @@ class Scheduler:
 class ContinuousBatcher:
     def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
                  max_step_tokens: Optional[int] = None, use_graph: bool = True, native: bool = True,
-                 prefill_chunk: Optional[int] = None, max_burst: int = 16):
+                 prefill_chunk: Optional[int] = None, max_burst: int = 1):
         p = model.lm_head.weight
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
@@ -186,8 +186,10 @@ class ContinuousBatcher:
         self._h_next = torch.zeros(max_batch, dtype=torch.long).pin_memory()
         # decode bursts: while the set of running requests cannot change (nothing to admit, nobody finishes), up to
         # `max_burst` steps are enqueued back to back -- each step's tokens feed the next ON THE DEVICE -- and the host
-        # reads all of them after ONE synchronisation (scheduling, three copies and a sync per step were ~0.13 ms of a
-        # 2.0 ms step at 32 slots).  Same tokens as step-by-step execution.
+        # reads all of them after ONE synchronisation.  Same tokens as step-by-step execution.  OFF by default (max_burst = 1):
+        # measured on 7B at 32 slots the host is not what bounds the loop (2.19 ms per step with a sync per step, 2.17 /
+        # 2.21 in bursts of 4 / 16, tools/burst_probe_serve.py) -- the step itself grows with the cached length (attention
+        # over 1024 (head, slot) workgroups: 2.00 ms at position 16, 2.18 at 36-84).
         self.max_burst = max(1, int(max_burst))
         self._graph_fb = None
         self._g_ring = torch.zeros(self.max_burst, max_batch, dtype=torch.long, device=self.dev)

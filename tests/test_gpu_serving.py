@@ -125,3 +125,29 @@ def test_chunked_prefill_produces_the_same_tokens(golden_dir, native):
             j = next(i for i in range(m) if a[i] != b[i])
             lg = model(torch.tensor([p + b[:j]], device=dev))[0, -1]
             assert abs(float(lg[a[j]] - lg[b[j]])) < 2e-2 * float(lg.abs().max())
+
+
+def test_decode_bursts_give_the_same_tokens(golden_dir):
+    """``max_burst`` > 1: while nothing can be admitted and nobody finishes, steps are enqueued back to back with each
+    step's tokens fed to the next ON THE DEVICE and read by the host after one synchronisation -- the same tokens, step
+    and token accounting as one synchronisation per step (requests of different lengths, more requests than slots)."""
+    from onebit_amd.serving import ContinuousBatcher
+    dev = torch.device("cuda:0")
+    model = _model(golden_dir, "b", dev)
+    V = model.config.vocab_size
+    g = torch.Generator().manual_seed(9)
+    reqs = [(torch.randint(0, V, (n,), generator=g).tolist(), m) for n, m in
+            [(6, 14), (3, 9), (11, 20), (2, 5), (7, 17), (4, 11)]]
+    outs, steps = {}, {}
+    for mb in (1, 8):
+        cb = ContinuousBatcher(model, max_batch=4, max_len=48, max_burst=mb)
+        assert cb._native is not None
+        rids = [cb.add_request(p, m) for p, m in reqs]
+        out = cb.run()
+        outs[mb] = [out[r] for r in rids]
+        steps[mb] = (cb.steps, cb.tokens_scheduled)
+        assert all(len(o) == m for o, (_, m) in zip(outs[mb], reqs))
+        if mb > 1:
+            assert cb._graph_fb is not None                       # bursts really ran
+    assert outs[1] == outs[8]
+    assert steps[1] == steps[8]
