@@ -126,6 +126,15 @@ int onebit_scale_layernorm(const float *z, const void *g, const void *bias_or_nu
  * u, y: [T, n] contiguous, fp16 or fp32 (dtype); stats, mean, rstd: fp32 device arrays.
  */
 int onebit_row_stats(const void *u, float *stats, int64_t T, int64_t n, int dtype, void *stream);
+/* ABI 7: the same statistics WITHOUT reading u again.  onebit_linear_forward with ONEBIT_FLAG_SKIP_LN | ONEBIT_FLAG_TILE_STATS
+ * (fp16; shapes for which onebit_linear_tile_stats_ok() is 1: the call takes the LDS-DMA GEMM -- pass its workspace or
+ * ONEBIT_FLAG_PRESCALED -- and N % 64 == 0) writes, from the GEMM's epilogue, per token and 64-row block the pair
+ * {sum, sum of squared deviations from the block mean} of the fp16 outputs into `u_or_null`, which in that call is NOT a
+ * second output but fp32 [T, N / 64, 2] (8-byte aligned).  onebit_tile_stats_combine reduces them to onebit_row_stats'
+ * format: stats[t] = {mean, sum of squared deviations} of the n = N columns.  T * N / 32 bytes instead of T * N * 2. */
+#define ONEBIT_FLAG_TILE_STATS 8u
+int onebit_linear_tile_stats_ok(int64_t T, int64_t K, int64_t N, int dtype);
+int onebit_tile_stats_combine(const float *tile_stats, float *stats, int64_t T, int64_t N, void *stream);
 int onebit_normalize_rows(const void *u, const float *mean, const float *rstd, const void *bias_or_null,
                           void *y, int64_t T, int64_t n, int dtype, void *stream);
 

@@ -18,6 +18,7 @@ ONEBIT_F16, ONEBIT_F32 = 0, 1
 FLAG_SKIP_LN = 1
 FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
 FLAG_PRESCALED = 4
+FLAG_TILE_STATS = 8
 ABI_VERSION = 7
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
@@ -36,6 +37,8 @@ SYMBOLS = {
     "onebit_scale_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _u, _vp]),
     "onebit_row_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "onebit_normalize_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "onebit_linear_tile_stats_ok": (_int, [_i64, _i64, _i64, _int]),
+    "onebit_tile_stats_combine": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "onebit_rows_res_ln_rms": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _f, _f, _vp]),
     "onebit_rows_swiglu": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
     "onebit_linear_prescaled_ok": (_int, [_i64, _i64, _i64, _int]),

@@ -479,11 +479,36 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3_f16_kernel(
         // (same wave wrote what it reads: no barrier, the compiler orders the LDS accesses with lgkmcnt)
         _Float16 *ub = u + (int64_t)(t0 + wt * 128) * N + n0 + wn * 64;
         const int trows = T - (t0 + wt * 128);
+        // Optional (ONEBIT_FLAG_TILE_STATS; `zp` is the output, N % 64 == 0 host-checked): LayerNorm partials of the rows
+        // just formed -- per token and 64-row block (sum, sum of squared deviations from the block mean) of the fp16 values
+        // being stored.  The 8 lanes that write a token's 128-byte segment hold its 64 values: two 8-lane DPP reductions.
+        // A consumer that needs row statistics (N-sharded layers: onebit_tile_stats_combine) reads T * N / 64 pairs
+        // instead of the T * N outputs again.
+        float *tsp = zp;
+        const int64_t ntile64 = N >> 6;
+        const int tile_idx = (n0 + wn * 64) >> 6;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = j * 8 + (lane >> 3), ch = lane & 7;
             const ob_half8 v = *reinterpret_cast<const ob_half8 *>(ep + row * EP + ch * 16);
             if (row < trows) *reinterpret_cast<ob_half8 *>(ub + (int64_t)row * N + ch * 8) = v;
+            if (tsp) {                                                              // (uniform)
+                float sm = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sm += (float)v[i];
+                sm += OB_DPP_F(sm, 0xB1, 0xF);                                      // quad_perm [1,0,3,2]
+                sm += OB_DPP_F(sm, 0x4E, 0xF);                                      // quad_perm [2,3,0,1]
+                sm += OB_DPP_F(sm, 0x141, 0xF);                                     // row_half_mirror: the other quad of the 8 lanes
+                const float mu = sm * 0.015625f;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m2 = __builtin_fmaf((float)v[i] - mu, (float)v[i] - mu, m2);
+                m2 += OB_DPP_F(m2, 0xB1, 0xF);
+                m2 += OB_DPP_F(m2, 0x4E, 0xF);
+                m2 += OB_DPP_F(m2, 0x141, 0xF);
+                if (ch == 0 && row < trows)
+                    *reinterpret_cast<ob_float2 *>(tsp + ((int64_t)(t0 + wt * 128 + row) * ntile64 + tile_idx) * 2) = (ob_float2){sm, m2};
+            }
         }
         return;
     }

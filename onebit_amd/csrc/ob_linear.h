@@ -267,6 +267,27 @@ __global__ __launch_bounds__(256) void ob_row_stats_kernel(const TD *__restrict_
     if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = q; }
 }
 
+// Row statistics from the LDS-DMA GEMM's per-(token, 64-row block) partials (ONEBIT_FLAG_TILE_STATS): one wave per token,
+// parallel-variance combine (Chan et al.); output in onebit_row_stats' format {mean, sum of squared deviations}.
+__global__ __launch_bounds__(256) void ob_tile_stats_combine_kernel(const float *__restrict__ tiles, float *__restrict__ stats, int T, int ntiles)
+{
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;                                                 // (wave-uniform)
+    const ob_float2 *p = reinterpret_cast<const ob_float2 *>(tiles) + (int64_t)t * ntiles;
+    float s = 0.f;
+    for (int j = lane; j < ntiles; j += 64) s += p[j][0];
+    s = ob_wave_sum(s);
+    const float mean = s / (64.0f * (float)ntiles);
+    float m2 = 0.f;
+    for (int j = lane; j < ntiles; j += 64) {
+        const ob_float2 v = p[j];
+        const float d = v[0] * 0.015625f - mean;
+        m2 += v[1] + 64.0f * d * d;
+    }
+    m2 = ob_wave_sum(m2);
+    if (lane == 0) { stats[2 * t] = mean; stats[2 * t + 1] = m2; }
+}
+
 template <typename TD>
 __global__ __launch_bounds__(256) void ob_normalize_rows_kernel(const TD *__restrict__ u, const float *__restrict__ mean,
                                                                 const float *__restrict__ rstd, const TD *__restrict__ bias,

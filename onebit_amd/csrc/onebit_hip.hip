@@ -365,7 +365,7 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
 {
     int rc = ob_check_linear("linear_forward", packed, ldw_bytes, x, h, T, K, N, dtype);
     if (rc) return rc;
-    if (flags & ~(ONEBIT_FLAG_SKIP_LN | ONEBIT_FLAG_PRESCALED)) return ob_fail(ONEBIT_E_FLAG, "linear_forward: unknown flags 0x%x", flags);
+    if (flags & ~(ONEBIT_FLAG_SKIP_LN | ONEBIT_FLAG_PRESCALED | ONEBIT_FLAG_TILE_STATS)) return ob_fail(ONEBIT_E_FLAG, "linear_forward: unknown flags 0x%x", flags);
     const bool prescaled = (flags & ONEBIT_FLAG_PRESCALED) != 0;
     if (prescaled && !(onebit_linear_prescaled_ok(T, K, N, dtype) && ldw_bytes % 16 == 0 && ob_aligned(packed, 16) && ob_aligned(x, 16) &&
                        N * ldw_bytes < ((int64_t)1 << 32)))
@@ -378,6 +378,17 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
     if (!ob_aligned(g, 2) || !ob_aligned(y, 16)) return ob_fail(ONEBIT_E_ALIGN, "linear_forward: y must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int skip = (flags & ONEBIT_FLAG_SKIP_LN) ? 1 : 0;
+    // ONEBIT_FLAG_TILE_STATS (with SKIP_LN, fp16): u_or_null is NOT a second output but fp32 [T, N / 64, 2] and receives the
+    // LayerNorm partials of the rows out of the LDS-DMA GEMM's epilogue; the call must take that GEMM (onebit_linear_tile_stats_ok)
+    float *tile_stats = nullptr;
+    bool tile_stats_done = false;
+    if (flags & ONEBIT_FLAG_TILE_STATS) {
+        if (!skip || dtype != ONEBIT_F16 || !u_or_null || !ob_aligned(u_or_null, 8) || !onebit_linear_tile_stats_ok(T, K, N, dtype))
+            return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_TILE_STATS needs SKIP_LN, fp16, a statistics buffer and a shape "
+                                          "onebit_linear_tile_stats_ok accepts");
+        tile_stats = (float *)u_or_null;
+        u_or_null = nullptr;
+    }
     if (dtype == ONEBIT_F16 && (K == 0 || ob_mfma_ok(packed, ldw_bytes, K, K, dtype))) {
         _Float16 *ubuf = (_Float16 *)(u_or_null ? u_or_null : y);
         if (K == 0) {
@@ -411,7 +422,8 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
                                    (const _Float16 *)h, (_Float16 *)workspace, T, (int)K);
                 a = (const _Float16 *)workspace;
             }
-            ob_launch_gemm3<false>((const uint32_t *)packed, ldw_bytes / 4, a, K, (const _Float16 *)g, ubuf, nullptr, T, K, N, s);
+            ob_launch_gemm3<false>((const uint32_t *)packed, ldw_bytes / 4, a, K, (const _Float16 *)g, ubuf, tile_stats, T, K, N, s);
+            tile_stats_done = tile_stats != nullptr;
             rc = ob_launch_status("linear_forward(gemm3)");
             if (rc) return rc;
         } else {
@@ -419,6 +431,9 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             rc = ob_launch_status("linear_forward(mm16)");
             if (rc) return rc;
         }
+        if (tile_stats && !tile_stats_done)
+            return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_TILE_STATS on a call that did not take the LDS-DMA GEMM "
+                                          "(workspace for the pre-scaled rows missing?)");
         if (skip && ubuf == y) return 0;
         ob_launch_ln_f16<false>(nullptr, (const _Float16 *)ubuf, (const _Float16 *)g, (const _Float16 *)bias,
                                 (_Float16 *)y, nullptr, T, N, ln_eps, skip, s);
@@ -509,6 +524,21 @@ extern "C" int onebit_scale_layernorm(const float *z, const void *g, const void 
                            (const float *)nullptr, (const float *)g, (const float *)bias, (float *)y,
                            (float *)u_or_null, (int)N, ln_eps, skip);
     return ob_launch_status("scale_layernorm");
+}
+
+extern "C" int onebit_linear_tile_stats_ok(int64_t T, int64_t K, int64_t N, int dtype)
+{
+    return (dtype == ONEBIT_F16 && T > 0 && K > 0 && N > 0 && N % 64 == 0 && K % 32 == 0 && ob_gemm3_ok(T, K, N)) ? 1 : 0;
+}
+
+extern "C" int onebit_tile_stats_combine(const float *tiles, float *stats, int64_t T, int64_t N, void *stream)
+{
+    if (T < 0 || N <= 0 || N % 64 != 0) return ob_fail(ONEBIT_E_SHAPE, "tile_stats_combine: N must be a positive multiple of 64");
+    if (T == 0) return 0;
+    if (!tiles || !stats || !ob_aligned(tiles, 8)) return ob_fail(ONEBIT_E_ARG, "tile_stats_combine: null or misaligned pointer");
+    hipLaunchKernelGGL(ob_tile_stats_combine_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, tiles, stats,
+                       (int)T, (int)(N / 64));
+    return ob_launch_status("tile_stats_combine");
 }
 
 extern "C" int onebit_row_stats(const void *u, float *stats, int64_t T, int64_t n, int dtype, void *stream)
@@ -746,7 +776,11 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     // (integer path: the digit image covers all KV * 8 chunks of a wave row, ob_decode.h)
     const size_t lds_i8 = (size_t)a.nproj * KV * OB_DEC_WAVES * 512 * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
-    const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2);
+    // single-chunk launches (o_proj: one tile, one 512-weight chunk per wave) take the integer path as well since round 4
+    // (8 MFMAs + 32 v_and instead of 16 MFMAs + 227 sign-expansion instructions: 3.54 -> 3.07 us per launch in a chain;
+    //  in rounds 1-2 the per-wave quantisation did not pay back).  OB_DEC_I8_SINGLE=0: A/B.
+    static const int i8_single = getenv("OB_DEC_I8_SINGLE") ? atoi(getenv("OB_DEC_I8_SINGLE")) : 1;
+    const bool use_i8 = aligned && ob_decode_math() == 1 && lds_i8 <= 160 * 1024 && (MT * KV >= 2 || i8_single);
     const size_t lds = use_i8 ? lds_i8 : (size_t)a.nproj * Kpad * 2 + (size_t)MT * OB_DEC_WAVES * 16 * 4 + 256 * 4;
     if (lds > 160 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: LDS need %zu > 160 KiB", lds);
     bool ok = false, hit = false;

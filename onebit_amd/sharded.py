@@ -246,6 +246,54 @@ def hip_rows_u(shard: NShard, x: torch.Tensor, prescaled: bool = False) -> torch
     return u
 
 
+def hip_rows_u_stats(shard: NShard, x: torch.Tensor, prescaled: bool = False):
+    """``hip_rows_u`` plus the local row statistics ``[T, 2]`` ({mean, sum of squared deviations}, the format of
+    ``hip_row_stats``) of the rows it just produced.  Where the call takes the LDS-DMA GEMM with whole 64-row blocks
+    (``onebit_linear_tile_stats_ok``) the statistics come out of the GEMM's epilogue as per-(token, 64-row block) partials
+    (ONEBIT_FLAG_TILE_STATS) and ``onebit_tile_stats_combine`` reduces T * n / 64 pairs -- u is NOT read again; elsewhere
+    this is ``hip_rows_u`` followed by ``hip_row_stats``."""
+    from . import _lib
+    from .bitnet import _dtype_code, _stream_ptr
+    lib = _lib.load()
+    T, K = x.shape
+    n = shard.n1 - shard.n0
+    code = _dtype_code(x.dtype)
+    w = shard.weight
+    with torch.cuda.device(x.device):
+        ok = (x.dtype == torch.float16 and shard.weight_scale.dtype == torch.float16 and w.stride(-1) == 1 and w.stride(0) % 16 == 0
+              and w.data_ptr() % 16 == 0 and bool(lib.onebit_linear_tile_stats_ok(T, K, n, code)))
+    if not ok:
+        u = hip_rows_u(shard, x, prescaled=prescaled)
+        return u, hip_row_stats(u)
+    u = torch.empty((T, n), dtype=x.dtype, device=x.device)
+    tiles = torch.empty((T, n // 64, 2), dtype=torch.float32, device=x.device)
+    ws_bytes = 0
+    if not prescaled:
+        with torch.cuda.device(x.device):
+            ws_bytes = lib.onebit_linear_workspace_bytes(T, K, n, code)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    st = torch.empty((T, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.onebit_linear_forward(w.data_ptr(), w.stride(0), x.data_ptr(), shard.input_factor.data_ptr(),
+                                       shard.weight_scale.data_ptr(), None, u.data_ptr(), tiles.data_ptr(),
+                                       None if ws is None else ws.data_ptr(), ws_bytes, T, K, n, code, 0.0,
+                                       _lib.FLAG_SKIP_LN | _lib.FLAG_TILE_STATS | (_lib.FLAG_PRESCALED if prescaled else 0),
+                                       _stream_ptr(x.device))
+        _lib.check(rc, "onebit_linear_forward(tile stats)")
+        rc = lib.onebit_tile_stats_combine(tiles.data_ptr(), st.data_ptr(), T, n, _stream_ptr(x.device))
+    _lib.check(rc, "onebit_tile_stats_combine")
+    return u, st
+
+
+def rows_and_stats(shard: NShard, x: torch.Tensor, rows_fn: Callable, stats_fn: Callable, prescaled: bool = False):
+    """(u, local row statistics) of an N-sharded layer: with the HIP callbacks one fused call (statistics out of the GEMM
+    epilogue where the shape allows, ``hip_rows_u_stats``), with stand-ins (gloo tests) the two callbacks in turn."""
+    if rows_fn is hip_rows_u and stats_fn is hip_row_stats:
+        return hip_rows_u_stats(shard, x, prescaled=prescaled)
+    u = rows_fn(shard, x, prescaled=True) if prescaled else rows_fn(shard, x)
+    return u, stats_fn(u)
+
+
 def hip_prescaled_ok(shard, T: int, device) -> bool:
     """True when a T-row fp16 call on this shard's matrix may take pre-scaled rows (the LDS-DMA GEMM)."""
     from . import _lib
@@ -301,9 +349,8 @@ def n_sharded_forward(shard: NShard, x: torch.Tensor, group=None, gather: bool =
     """x: [T, K] full-width activations on every rank.  Returns this rank's columns y[:, n0:n1]
     (``gather=False``) or the complete y [T, N] (``gather=True``, needs equal slices)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    u = rows_fn(shard, x)                                              # [T, n_p] in x.dtype
+    u, st = rows_and_stats(shard, x, rows_fn, stats_fn)                # [T, n_p] in x.dtype; [T, 2]: local mean, local M2
     N = shard.out_features
-    st = stats_fn(u)                                                   # [T, 2]: local mean, local M2
     n_p = float(shard.n1 - shard.n0)
     if world > 1:
         # parallel variance (Chan et al.): N*mean = sum n_p*mean_p;  M2 = sum M2_p + sum n_p*(mean_p - mean)^2

@@ -327,9 +327,16 @@ class TensorParallelPrefill:
         world = self._world()
         st = torch.stack(parts, dim=0)                                           # [P, T, 2]
         P, T = st.shape[0], st.shape[1]
-        Ns = torch.tensor([float(sh.out_features) for sh in shards], device=st.device).view(P, 1)
+        # (the row counts are constants of the plan: built once per (shapes, device) -- a torch.tensor(..., device=) here
+        #  was a blocking host -> device copy twice per layer)
+        key = (tuple((sh.out_features, sh.n1 - sh.n0) for sh in shards), st.device)
+        cache = self.__dict__.setdefault("_stat_consts", {})
+        if key not in cache:
+            cache[key] = (torch.tensor([float(sh.out_features) for sh in shards], device=st.device).view(P, 1),
+                          torch.tensor([float(sh.n1 - sh.n0) for sh in shards], device=st.device))
+        Ns, cnt_c = cache[key]
         if world > 1:
-            cnt = torch.tensor([float(sh.n1 - sh.n0) for sh in shards], device=st.device)
+            cnt = cnt_c
             all_st = torch.empty((world,) + tuple(st.shape), dtype=st.dtype, device=st.device)
             all_cnt = torch.empty((world, P), dtype=torch.float32, device=st.device)
             dist.all_gather_into_tensor(all_st.view(world * P * T, 2), st.contiguous().view(P * T, 2), group=self.group)
@@ -379,11 +386,13 @@ class TensorParallelPrefill:
 
         for li, (layer, sh) in enumerate(zip(layers, self.layers)):
             # --- q | k | v of the local heads for all tokens; LayerNorm over the COMPLETE rows via combined statistics
+            # (u and its local row statistics in one call: out of the GEMM epilogue where the shape allows, sharded.rows_and_stats)
             if xs is not None:
-                u_q, u_k, u_v = (rows_fn(s_, a_, prescaled=True) for s_, a_ in zip((sh.q, sh.k, sh.v), xs))
+                (u_q, s_q), (u_k, s_k), (u_v, s_v) = (sharded.rows_and_stats(s_, a_, rows_fn, stats_fn, prescaled=True)
+                                                      for s_, a_ in zip((sh.q, sh.k, sh.v), xs))
             else:
-                u_q, u_k, u_v = rows_fn(sh.q, x), rows_fn(sh.k, x), rows_fn(sh.v, x)
-            st6 = self._complete_stats([stats_fn(u_q), stats_fn(u_k), stats_fn(u_v)], [sh.q, sh.k, sh.v], 1e-5)
+                (u_q, s_q), (u_k, s_k), (u_v, s_v) = (sharded.rows_and_stats(s_, x, rows_fn, stats_fn) for s_ in (sh.q, sh.k, sh.v))
+            st6 = self._complete_stats([s_q, s_k, s_v], [sh.q, sh.k, sh.v], 1e-5)
             q, k, v = G.qkv_rope(u_q[:T], u_k[:T], u_v[:T], st6[:T], cos, sin, B, S, Hl, Hkvl, D, 1e-5)
             self.kv.append((k, v))
             # --- o_proj on the local heads' columns -> ONE reduction -> u on own rows -> LayerNorm + residual + RMSNorm fused
@@ -399,14 +408,14 @@ class TensorParallelPrefill:
             if pre((sh.gate, sh.up)):
                 h_own, (ag, au) = G.res_ln_rms(h_own, u_o, layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5,
                                                h_next=(sh.gate.input_factor, sh.up.input_factor))
-                u_g, u_u = rows_fn(sh.gate, ag, prescaled=True), rows_fn(sh.up, au, prescaled=True)
+                (u_g, s_g), (u_u, s_u) = (sharded.rows_and_stats(s_, a_, rows_fn, stats_fn, prescaled=True) for s_, a_ in ((sh.gate, ag), (sh.up, au)))
             else:
                 h_own, x2_own = G.res_ln_rms(h_own, u_o, layer.post_attention_layernorm.weight, cfg.rms_norm_eps, 1e-5)
                 x2 = self._all_gather_rows(x2_own)
-                u_g, u_u = rows_fn(sh.gate, x2), rows_fn(sh.up, x2)
+                (u_g, s_g), (u_u, s_u) = (sharded.rows_and_stats(s_, x2, rows_fn, stats_fn) for s_ in (sh.gate, sh.up))
             self.exchanges += 1
             # --- MLP
-            st4 = self._complete_stats([stats_fn(u_g), stats_fn(u_u)], [sh.gate, sh.up], 1e-5)
+            st4 = self._complete_stats([s_g, s_u], [sh.gate, sh.up], 1e-5)
             down_pre = direct and sharded.hip_prescaled_ok(NShard(sh.down.weight, sh.down.input_factor, sh.down.weight_scale, None, 0,
                                                                   sh.down.out_features, sh.down.k1 - sh.down.k0, sh.down.out_features), Tp, dev)
             act = G.swiglu(u_g, u_u, st4, 1e-5, sh.down.input_factor) if down_pre else G.swiglu(u_g, u_u, st4, 1e-5)

@@ -337,3 +337,36 @@ def test_skinny_gemm_on_prescaled_rows_vs_oracle(coracle, K, N, T):
     for t in range(T):
         _check_u(u2[t], u_ref[t], "K=%d N=%d T=%d row %d" % (K, N, T, t))
     assert (u1 != u2).mean() <= 0.02
+
+
+@pytest.mark.parametrize("T,K,N,prescaled", [(4096, 4096, 4096, False), (4096, 4096, 11008, True), (8192, 4096, 5504, True),
+                                              (4096, 11008, 4096, False), (4000, 4096, 2752, False)])
+def test_gemm_epilogue_tile_stats_equal_row_stats(T, K, N, prescaled):
+    """ONEBIT_FLAG_TILE_STATS: the LDS-DMA GEMM's epilogue publishes per-(token, 64-row block) LayerNorm partials of the
+    rows it stores and onebit_tile_stats_combine reduces them -- the row statistics an N-sharded layer exchanges, without
+    reading u again (tensor-parallel prefill).  Same u bit for bit as the plain call; {mean, M2} equal to onebit_row_stats'
+    exact two-pass values of that u up to fp32 summation order.  Shapes: full rows, N-slices of 2 / 4 ranks (whole
+    64-row blocks), a ragged token count."""
+    from onebit_amd import _lib
+    from onebit_amd.sharded import NShard, hip_row_stats, hip_rows_u, hip_rows_u_stats
+    dev = torch.device("cuda:0")
+    m, packed, h, g = _mk(K, N, 50 + N % 7, dev)
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    x = torch.randn(T, K, generator=gen).half().to(dev)
+    a = (x * m.input_factor.data).contiguous() if prescaled else x
+    sh = NShard(m.weight.data, m.input_factor.data, m.weight_scale.data, None, 0, N, K, N)
+    assert _lib.load().onebit_linear_tile_stats_ok(T, K, N, 0) == 1, "this shape is expected on the LDS-DMA GEMM"
+    u_ref = hip_rows_u(sh, a, prescaled=prescaled)
+    st_ref = hip_row_stats(u_ref)
+    u, st = hip_rows_u_stats(sh, a, prescaled=prescaled)
+    assert torch.equal(u, u_ref)
+    assert st.shape == (T, 2)
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), st_ref[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), st_ref[:, 1].cpu().numpy(), rtol=2e-5)
+    # a shape the flag cannot serve (N not a multiple of 64) falls back to the two-call form with the same results
+    sh2 = NShard(m.weight.data[:1376], m.input_factor.data, m.weight_scale.data[:1376], None, 0, 1376, K, N) if N >= 1376 else None
+    if sh2 is not None:
+        assert _lib.load().onebit_linear_tile_stats_ok(T, K, 1376, 0) == 0
+        u2, st2 = hip_rows_u_stats(sh2, a, prescaled=prescaled)
+        assert torch.equal(u2, u_ref[:, :1376])
+        np.testing.assert_allclose(st2.cpu().numpy(), hip_row_stats(u2).cpu().numpy(), rtol=1e-6)
