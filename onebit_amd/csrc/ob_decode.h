@@ -1251,16 +1251,35 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
     ob_half8 kreg[NI], vreg[NI];
     // everything that does not depend on the position is requested before the position is read (batched step: the
     // position, then the K / V rows, then the rest were three dependent round trips)
-    ObTileStatsRt tq, tk, tv;
-    if (PST) { ob_tiles_load_rt(tq, A.st_q, NQ, lane); ob_tiles_load_rt(tk, A.st_k, NK, lane); ob_tiles_load_rt(tv, A.st_v, NK, lane); }
-    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
+    // PST (round 4): ROLES.  Wave 0 normalises and rotates q, wave 1 k, wave 2 v -- each combines only ITS vector's tile
+    // partials (every wave combining all three and two waves doing all the LayerNorm / RoPE arithmetic was ~100
+    // instructions of the chain in front of the first barrier) and a lane holds both elements of a rotate_half pair.
     const int half = D >> 1;
+    const int role = __builtin_amdgcn_readfirstlane(wave);
+    const bool ract = role < 3 && lane < half;
+    const int d0 = min(lane, half - 1), d1 = d0 + half;
+    ObTileStatsRt tr;
+    _Float16 ur0 = (_Float16)0, ur1 = (_Float16)0, rc0 = (_Float16)0, rs0 = (_Float16)0, rc1 = (_Float16)0, rs1 = (_Float16)0;
+    const float *st_r = role == 0 ? A.st_q : (role == 1 ? A.st_k : A.st_v);
+    const int n_r = role == 0 ? NQ : NK;
+    if (PST) {
+        const _Float16 *ub = role == 0 ? A.u_q + head * D : (role == 1 ? A.u_k + kvh * D : A.u_v + kvh * D);
+        if (role < 3) {                                                           // (wave-uniform)
+            ob_tiles_load_rt(tr, st_r, n_r, lane);
+            ur0 = ub[d0]; ur1 = ub[d1];
+            if (A.rope_cur) { rc0 = A.rope_cur[d0]; rs0 = A.rope_cur[D + d0]; rc1 = A.rope_cur[d1]; rs1 = A.rope_cur[D + d1]; }
+        }
+    }
+    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
     const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
-    const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
-    const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
+    _Float16 uqh = (_Float16)0, ukh = (_Float16)0, uvh = (_Float16)0, uqp = (_Float16)0, ukp = (_Float16)0;
+    if (!PST) {
+        uqh = A.u_q[head * D + dq]; ukh = A.u_k[kvh * D + dq]; uvh = A.u_v[kvh * D + dq];
+        uqp = A.u_q[head * D + dp]; ukp = A.u_k[kvh * D + dp];
+    }
     const _Float16 hnx = A.h_next ? A.h_next[head * D + dq] : (_Float16)1;
     _Float16 cosh_ = (_Float16)0, sinh_ = (_Float16)0;
-    if (A.rope_cur) { cosh_ = A.rope_cur[dq]; sinh_ = A.rope_cur[D + dq]; }      // requested with everything else (uniform branch)
+    if (!PST && A.rope_cur) { cosh_ = A.rope_cur[dq]; sinh_ = A.rope_cur[D + dq]; }      // requested with everything else (uniform branch)
     int pos_early = 0;
     if (!BLIND) {
         pos_early = *A.pos;
@@ -1284,16 +1303,40 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
     if (!BLIND && !live) return;                  // idle slot (batched step): uniform, before any barrier
     const int pos = live ? pos_raw : 0;
     const int L = pos + 1;
-    if (!A.rope_cur) { cosh_ = A.cos[(int64_t)pos * D + dq]; sinh_ = A.sin[(int64_t)pos * D + dq]; }
+    if (!A.rope_cur) {
+        if (PST) {
+            if (role < 2) {
+                rc0 = A.cos[(int64_t)pos * D + d0]; rs0 = A.sin[(int64_t)pos * D + d0];
+                rc1 = A.cos[(int64_t)pos * D + d1]; rs1 = A.sin[(int64_t)pos * D + d1];
+            }
+        } else { cosh_ = A.cos[(int64_t)pos * D + dq]; sinh_ = A.sin[(int64_t)pos * D + dq]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // LayerNorm statistics of the three rows: from the producer's tile partials (every wave, no
     // barrier), or recomputed from the rows by each workgroup
-    float mq, rq, mk, rk, mv, rv;
+    float mq = 0.f, rq = 0.f, mk = 0.f, rk = 0.f, mv = 0.f, rv = 0.f;
     if (PST) {
-        ob_tiles_combine_rt(tq, A.st_q, NQ, A.ln_eps, lane, mq, rq);
-        ob_tiles_combine_rt(tk, A.st_k, NK, A.ln_eps, lane, mk, rk);
-        ob_tiles_combine_rt(tv, A.st_v, NK, A.ln_eps, lane, mv, rv);
+        if (role < 3) {                                                           // (wave-uniform)
+            float mr, rr;
+            ob_tiles_combine_rt(tr, st_r, n_r, A.ln_eps, lane, mr, rr);
+            // apply_rotary_pos_emb (:175-181): x*cos + rotate_half(x)*sin, each op rounded to fp16; v: LayerNorm only
+            const float y0 = ob_ln_apply((float)ur0, mr, rr), y1 = ob_ln_apply((float)ur1, mr, rr);
+            float e0 = y0, e1 = y1;
+            if (role < 2) {
+                e0 = ob_round_h(ob_round_h(y0 * (float)rc0) + ob_round_h(-y1 * (float)rs0));
+                e1 = ob_round_h(ob_round_h(y1 * (float)rc1) + ob_round_h(y0 * (float)rs1));
+            }
+            _Float16 *dst = role == 0 ? q_s : (role == 1 ? k_s : v_s);
+            if (ract) {
+                dst[d0] = (_Float16)e0; dst[d1] = (_Float16)e1;
+                if (role > 0 && live && head % (H / Hkv) == 0) {      // one workgroup per kv head appends to the cache
+                    _Float16 *cr = (role == 1 ? A.kcache : A.vcache) + ((int64_t)kvh * A.max_len + pos) * D;
+                    cr[d0] = (_Float16)e0; cr[d1] = (_Float16)e1;
+                }
+            }
+            for (int d = D + lane; d < 128; d += 64) dst[d] = (_Float16)0;     // zero padding beyond the head dimension
+        }
     } else {
         const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1311,7 +1354,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         ob_ln_stats(s[2], s[3], ck, NK, A.ln_eps, mk, rk);
         ob_ln_stats(s[4], s[5], cv, NK, A.ln_eps, mv, rv);
     }
-    if (tid < 128) {
+    if (!PST && tid < 128) {
         float qe = 0.f, ke = 0.f, ve = 0.f;
         if (tid < D) {
             // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16

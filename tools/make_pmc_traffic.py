@@ -6,8 +6,10 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import csrc_sha
-names = {"<1, 1, true, 2, 1, 3, true>": "qkv", "<1, 1, true, 0, 0, 1, false>": "o", "<1, 3, true, 2, 1, 2, true>": "gate_up",
-         "<3, 1, true, 3, 1, 1, true>": "down"}
+# template arguments: KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP (round 4: q|k|v and gate|up are one-projection-per-workgroup
+# launches, o_proj runs on the integer path)
+names = {"<1, 4, true, 2, 1, 1, true, true>": "qkv", "<1, 1, true, 0, 1, 1, false, false>": "o", "<1, 6, true, 2, 1, 1, true, true>": "gate_up",
+         "<3, 1, true, 3, 1, 1, true, false>": "down"}
 out = {}
 for line in open(sys.argv[1]):
     m = re.search(r"FETCH_SIZE avg ([0-9.]+)", line)
