@@ -321,3 +321,69 @@ def test_engine_bias_checkpoint_names_the_remedy(golden_dir):
         DecodeEngine(model, max_len=32)
     out = model.generate(torch.tensor([[1, 2, 3]], device=dev), max_new_tokens=2)      # the named remedy works
     assert out.shape == (1, 5)
+
+
+@pytest.mark.parametrize("K,Ns", [
+    (4096, (2048, 2048)),             # 2 x 128 tiles            -> 1 slot per workgroup
+    (4096, (4096, 4096)),             # 2 x 256                  -> 2
+    (4096, (6144, 6144)),             # 2 x 384                  -> 3
+    (4096, (10240, 10240)),           # 2 x 640                  -> 5
+    (4096, (16384, 16384)),           # 2 x 1024                 -> 8
+    (4096, (4096, 1024, 1024)),       # grouped-query shapes: 256 + 64 + 64 tiles -> 2, unequal workgroup ranges
+    (8192, (8192, 8192, 8192)),       # two 512-weight chunks per wave (KV = 2), 3 x 512 tiles -> 6
+    (8192, (14336, 14336)),           # KV = 2, 2 x 896 -> 7
+    (2048, (2072, 1048)),             # K below one chunk row (waves 4..7 own no chunk), ragged last tiles (N % 16 != 0: no partials)
+])
+@pytest.mark.parametrize("use_stats", [True, False])
+def test_one_projection_per_workgroup_launches(coracle, K, Ns, use_stats):
+    """The q|k|v / gate|up launches of the decode step deal their workgroups to the projections (ob_decode.h, WGP): every
+    slot count the host can pick (1 .. 8), one and two chunks per wave, unequal projection heights, a chunk row that only
+    half the waves populate and ragged last tiles -- each projection's pre-LayerNorm u against the oracle fed with the
+    normalised vector the kernel itself formed (u within 2 fp16 ulps, different at all on < 3 % of the elements), and the
+    per-tile LayerNorm partials it publishes against the stored u."""
+    from onebit_amd import BitLinearInf
+    from onebit_amd.engine import PRO_PLAIN, PRO_RES_LN_RMS, fused_gemv, tile_stats_floats
+    dev = torch.device("cuda:0")
+    f16 = torch.float16
+    rng = np.random.default_rng(K + sum(Ns))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    mods, raw = [], []
+    for i, N in enumerate(Ns):
+        packed = rng.integers(0, 256, (N, K // 8), dtype=np.uint8).view(np.int8)
+        flip = lambda n: np.where(rng.random(n) < 0.1, -1.0, 1.0)
+        h = (0.1 * (0.5 + rng.random(K)) * flip(K)).astype(np.float16)
+        g = (0.1 * (0.5 + rng.random(N)) * flip(N)).astype(np.float16)
+        m = BitLinearInf(K, N, dtype=f16).to(dev)
+        m.weight.data, m.input_factor.data, m.weight_scale.data = t(packed), t(h), t(g)
+        mods.append(m); raw.append((packed, h, g))
+    # a producer for u_prev and its partials: any PLAIN launch of width K
+    prod = BitLinearInf(K, K, dtype=f16).to(dev)
+    prod.weight.data = t(rng.integers(0, 256, (K, K // 8), dtype=np.uint8).view(np.int8))
+    prod.input_factor.data = t((0.1 * (0.5 + rng.random(K))).astype(np.float16))
+    prod.weight_scale.data = t((0.1 * (0.5 + rng.random(K))).astype(np.float16))
+    u_prev = torch.empty(K, dtype=f16, device=dev)
+    st_prev = torch.full((tile_stats_floats(K),), float("nan"), dtype=torch.float32, device=dev)
+    fused_gemv([prod], [u_prev], PRO_PLAIN, xin=t(rng.standard_normal(K).astype(np.float16)), stats_out=[st_prev])
+    hres = rng.standard_normal(K).astype(np.float16)
+    rms_w = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    outs = [torch.empty(N, dtype=f16, device=dev) for N in Ns]
+    sts = [torch.full((tile_stats_floats(N),), float("nan"), dtype=torch.float32, device=dev) for N in Ns]
+    hout = torch.empty(K, dtype=f16, device=dev)
+    kw = dict(st_prev=st_prev) if use_stats else {}
+    fused_gemv(mods, outs, PRO_RES_LN_RMS, hres_in=t(hres), u_prev=u_prev, hres_out=hout, rms_w=t(rms_w), stats_out=sts, **kw)
+    hk = hout.cpu().numpy().astype(np.float32)
+    rs = 1.0 / np.sqrt((hk.astype(np.float64) ** 2).mean() + 1e-6)
+    xn = (rms_w * (hk * rs).astype(np.float16)).astype(np.float16)
+    for (packed, h, g), o, st, N in zip(raw, outs, sts, Ns):
+        _, u_ref = coracle.forward_f16(packed, xn[None], h, g, None, return_pre_ln=True)
+        got, ref = o.cpu().numpy().astype(np.float32), u_ref[0].astype(np.float32)
+        ulp = np.maximum(np.abs(ref), 2.0 ** -12) * 2.0 ** -10
+        assert (np.abs(got - ref) <= 2.001 * ulp).all(), (N, float((np.abs(got - ref) / ulp).max()))
+        assert (got != ref).mean() <= 0.03, (N, float((got != ref).mean()))
+        if N % 16 == 0:
+            uu = got.astype(np.float64).reshape(-1, 16)
+            s = uu.sum(1)
+            m2 = ((uu - s[:, None] / 16.0) ** 2).sum(1)
+            pub = st.cpu().numpy()[: 2 * (N // 16)].reshape(-1, 2)
+            np.testing.assert_allclose(pub[:, 0], s, rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(pub[:, 1], m2, rtol=1e-4, atol=1e-4)

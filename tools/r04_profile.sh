@@ -13,6 +13,7 @@ echo "rc2=$?"; python $R/tools/pmc_summary.py /tmp/p_fetch > $O/pmc_FETCH_SIZE.t
 # 3. issue / wait counters of the decode kernels
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d /tmp/p_issue -- python $R/bench.py $D > /dev/null 2> $O/issue.err
 echo "rc3=$?"; python $R/tools/pmc_summary.py /tmp/p_issue | grep "ob_dec" > $O/pmc_decode_issue.txt; tail -1 $O/issue.err
+if [ -z "$R04_SHORT" ]; then
 # 4. prefill layer [16384, 4096] -> 11008: kernel stats, then the MFMA counters of the same command
 OB_ONE=1 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_pl -- python $R/tools/prefill_probe.py > $O/prefill_layer.txt 2> $O/prefill_layer.err
 echo "rc4=$?"; cp $(find /tmp/p_pl -name "*kernel_stats.csv" | head -1) $O/prefill_layer_kernel_stats.csv
@@ -26,6 +27,7 @@ timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 echo "rc7=$?"; python $R/tools/pmc_summary.py /tmp/p_at | grep "flash" > $O/pmc_attention.txt
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/p_at2 -- python $R/tools/attn_probe.py > /dev/null 2>> $O/attn_pmc.err
 echo "rc8=$?"; python $R/tools/pmc_summary.py /tmp/p_at2 | grep "flash" >> $O/pmc_attention.txt
+fi
 cd $R
 timeout 100 python tools/decode_kernels.py > $O/decode_insitu.txt 2>&1
 timeout 100 python tools/serve_kernels.py 7b > $O/serve_kernels.txt 2>&1
