@@ -378,8 +378,16 @@ def test_one_projection_per_workgroup_launches(coracle, K, Ns, use_stats):
         _, u_ref = coracle.forward_f16(packed, xn[None], h, g, None, return_pre_ln=True)
         got, ref = o.cpu().numpy().astype(np.float32), u_ref[0].astype(np.float32)
         ulp = np.maximum(np.abs(ref), 2.0 ** -12) * 2.0 ** -10
-        assert (np.abs(got - ref) <= 2.001 * ulp).all(), (N, float((np.abs(got - ref) / ulp).max()))
-        assert (got != ref).mean() <= 0.03, (N, float((got != ref).mean()))
+        # The oracle's input vector is rebuilt on the host from the residual stream the kernel wrote (exact rsqrt); the
+        # kernel's hardware rsq may round ONE or two of the K normalised inputs to the neighbouring fp16 value.  Such a flip
+        # moves EVERY z by up to one ulp of that input (2^-13 for |a| < 0.25), i.e. every u by up to 2^-13 * |g| -- invisible
+        # against 2 ulps of a typical output, several ulps of an output that cancelled to ~1e-3.  Hence the absolute term
+        # (two flips' worth) and the wider "different at all" fraction; a wrong tile, slot or projection is off by O(1).
+        atol = 2.0 * 2.0 ** -13 * float(np.abs(g.astype(np.float32)).max())
+        assert (np.abs(got - ref) <= 2.001 * ulp + atol).all(), (N, float((np.abs(got - ref) / ulp).max()))
+        assert (got != ref).mean() <= 0.08, (N, float((got != ref).mean()))
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel <= 2e-4, (N, rel)
         if N % 16 == 0:
             uu = got.astype(np.float64).reshape(-1, 16)
             s = uu.sum(1)
