@@ -1698,7 +1698,7 @@ extern "C" int onebit_attention_prefill(const void *q, const void *k_cache, cons
     if (nmb * n_heads * B > 0x7fffffffLL || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "attention_prefill: dimension too large");
     ObFlashArgs a = {(const _Float16 *)q, (const _Float16 *)k_cache, (const _Float16 *)v_cache, (_Float16 *)o, (const _Float16 *)h_next,
                      (int)S, n_heads, n_kv_heads, (int)max_len, (int)past_len, 1.4426950408889634f / sqrtf((float)head_dim), (int)nmb};
-    const dim3 grid((unsigned)(nmb * n_heads * B));
+    const dim3 grid((unsigned)(((nmb + 1) / 2) * n_heads * B));      // a workgroup takes a heavy and a light query block
     if (head_dim == 128) hipLaunchKernelGGL((ob_flash_fwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((ob_flash_fwd_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return ob_launch_status("attention_prefill");
