@@ -22,8 +22,21 @@
 // running output is a per-lane scalar.  Output: 4 consecutive d of one query per lane and tile, written token-major
 // [B, S, H, D] = the rows o_proj consumes, optionally already multiplied by o_proj's input_factor (bitnet.py:113) so
 // that the projection runs with ONEBIT_FLAG_PRESCALED.
-// Causality: key blocks above the diagonal are never loaded; diagonal blocks are masked per element; query blocks are
-// issued heaviest first.
+// Causality: key blocks above the diagonal are never loaded; diagonal blocks are masked per element (a separate instance of the
+// block body, so the blocks below the diagonal carry no mask code); a workgroup takes query block n - 1 - j and then block j of
+// its (sequence, head), so every workgroup sweeps the same number of key blocks.
+// Round 4 (546 -> 654 TFLOP/s at 8 x 2048 x 32 x 128; every step measured with tools/flash_lab.hip):
+//   * K and V tiles double-buffered in LDS, ONE barrier per key block; rows unpadded and XOR-swizzled -- no bank conflict left
+//     (SQ_LDS_BANK_CONFLICT 0, was 45 % of the LDS cycles)
+//   * K / V pieces by buffer loads: lane-constant offset + one add per block, rows past the last key read as zeros
+//   * the running maximum moves only when a tile exceeds it by more than 2^8 (the rescale of the output was taken for half the
+//     blocks on random scores)
+//   * issue order pinned where hipcc's own choice left LDS latency in front of the matrix pipe (K fragments 2 tiles ahead, V
+//     fragments of the first 32 keys requested before the softmax arithmetic)
+// What bounds it now (ablations in flash_lab: no softmax arithmetic 755, no staging 821, neither 1039 TFLOP/s): the softmax VALU
+// work and the K / V staging of a wave run in series with its MFMAs, and the second wave of the SIMD covers only part of it.
+// A one-wave-per-SIMD, 64-queries-per-wave variant with hand-interleaved softmax was built and measured slower (565):
+// tools/attic/ob_flash64_experiment.h.
 #pragma once
 #include <type_traits>
 #include "ob_common.h"
@@ -67,12 +80,6 @@ __device__ __forceinline__ float ob_fl_col_sum(float v)
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-#ifndef OB_FL_SPREAD
-#define OB_FL_SPREAD 0         // staging stores / loads spread behind the MFMAs (0: in two bursts)
-#endif
-#ifndef OB_FL_SORD
-#define OB_FL_SORD 0
-#endif
 #ifndef OB_FL_ABL
 #define OB_FL_ABL 0             // tools/flash_lab.hip ablations (timing only): 1 = no softmax arithmetic, 2 = no K / V staging in the loop
 #endif
@@ -220,14 +227,13 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
                 for (int qt = 0; qt < 2; ++qt) sc[i / DK][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i / DK][i % DK], qf[qt][i % DK], sc[i / DK][qt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + 2 * DK < 4 * DK) read_k(i + 2 * DK);
-                if (OB_FL_SPREAD && (i & 1) && do_store) store_piece(buf ^ 1, i >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!OB_FL_SPREAD && do_store) store_block(buf ^ 1);
+            if (do_store) store_block(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         } else if (do_store) store_block(buf ^ 1);
         OB_FL_T(1);
-        if ((!OB_FL_SPREAD || !active) && do_load) load_block(kb + 2);
+        if (do_load) load_block(kb + 2);
         OB_FL_T(2);
         if (active) {
             ob_half8 vf[2][DT];
@@ -314,16 +320,9 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt) acc_o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks][dt], pb[qt][ks], acc_o[dt][qt], 0, 0, 0);
-                    if (OB_FL_SPREAD && ((ks * DT + dt) & 1)) {       // one load of block kb + 2 behind every fourth MFMA
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int j = (ks * DT + dt) >> 1;
-                        if (do_load && j < 2 * KLD) load_piece(kb + 2, j);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
         }
         OB_FL_T(4);
         __syncthreads();                        // block kb + 1 is complete in the other buffer; this one may be overwritten

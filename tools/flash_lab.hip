@@ -9,6 +9,9 @@
 #include <stdlib.h>
 #include <vector>
 #include "ob_flash.h"
+#ifdef FL_K64
+#include "attic/ob_flash64_experiment.h"
+#endif
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static inline float rnd_uniform()
@@ -34,7 +37,15 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dk, k.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dv, v.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemset(d_o, 0, 2 * n));
+#ifdef FL_K64
+#define FL_KERNEL ob_flash_fwd64_kernel<D>
+    const int nmb = (S + OB_FL64_BM - 1) / OB_FL64_BM;
+    const int dyn0 = OB_FL64_LDS;
+#else
+#define FL_KERNEL ob_flash_fwd_kernel<D>
     const int nmb = (S + OB_FL_BM - 1) / OB_FL_BM;
+    const int dyn0 = 0;
+#endif
     ObFlashArgs a = {dq, dk, dv, d_o, nullptr, S, H, H, S, 0, 1.4426950408889634f / sqrtf((float)D), nmb};
 #ifdef OB_FL_TRACE
     unsigned long long *dtr;
@@ -43,14 +54,14 @@ int main(int argc, char **argv)
     a.trace = dtr;
 #endif
     const dim3 grid((unsigned)(((nmb + 1) / 2) * H * B));
-    const int dyn = getenv("FL_DYN") ? atoi(getenv("FL_DYN")) : 0;       // unused dynamic LDS: FL_DYN=40000 leaves room for ONE workgroup per CU
-    if (dyn) CK(hipFuncSetAttribute((const void *)ob_flash_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    const int dyn = dyn0 + (getenv("FL_DYN") ? atoi(getenv("FL_DYN")) : 0);       // unused dynamic LDS: FL_DYN=40000 leaves room for ONE workgroup per CU
+    if (dyn) CK(hipFuncSetAttribute((const void *)FL_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((ob_flash_fwd_kernel<D>), grid, dim3(OB_FL_THREADS), dyn, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(OB_FL_THREADS), dyn, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ob_flash_fwd_kernel<D>), grid, dim3(OB_FL_THREADS), dyn, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(OB_FL_THREADS), dyn, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double flop = 4.0 * B * H * (double)S * S * D / 2;
