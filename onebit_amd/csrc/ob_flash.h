@@ -34,9 +34,13 @@
 //   * issue order pinned where hipcc's own choice left LDS latency in front of the matrix pipe (K fragments 2 tiles ahead, V
 //     fragments of the first 32 keys requested before the softmax arithmetic)
 // What bounds it now (ablations in flash_lab: no softmax arithmetic 755, no staging 821, neither 1039 TFLOP/s): the softmax VALU
-// work and the K / V staging of a wave run in series with its MFMAs, and the second wave of the SIMD covers only part of it.
-// A one-wave-per-SIMD, 64-queries-per-wave variant with hand-interleaved softmax was built and measured slower (565):
-// tools/attic/ob_flash64_experiment.h.
+// work and the K / V staging of a wave run in series with its MFMAs, and the second wave of the SIMD covers little of it.  Three
+// rearrangements meant to force the overlap were built, are correct, and measured SLOWER; they are kept under tools/attic with
+// their numbers: one wave per SIMD with 64 queries per wave and hand-interleaved softmax (565; ob_flash64_experiment.h), an
+// 8-wave ping-pong where one wave of a SIMD streams MFMAs while its partner does only VALU work (599; ob_flash_pp.h -- its
+// ablations show MFMA-only time + VALU-only time = total time: two waves of a SIMD do not overlap the two kinds of work), and
+// this kernel with the two query tiles of a wave taken in turn, one tile's exponentials interleaved with the other's MFMAs
+// (577; ob_flash_split_experiment.h).
 #pragma once
 #include <type_traits>
 #include "ob_common.h"

@@ -1,8 +1,10 @@
 // Development bench for the prefill attention kernel, without torch: random fp16 q / k / v at the BASELINE config-3 shape,
 // timed with HIP events, sampled query rows checked against an fp32 host restatement of modeling_bitllama.py:546-563, and
 // (built with -DOB_FL_TRACE) an s_memtime timeline of two workgroups.  Variants are compile-time switches of ob_flash.h:
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ionebit_amd/csrc [-DOB_FL_...] tools/flash_lab.hip -o tools/flash_lab
-//   tools/flash_lab [B S H reps]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ionebit_amd/csrc -Itools [-DOB_FL_...] tools/flash_lab.hip -o tools/flash_lab
+//   tools/flash_lab [B S H reps label]          (FL_DYN=40000 in the environment: one workgroup per CU)
+// -DOB_FL_ABL=1|2|3: no softmax arithmetic / no staging / neither (timing only); -DOB_FL_DEFER_THR=0.0f: rescale on every new maximum;
+// -DFL_K64 / -DFL_PP: the experiments under tools/attic instead of the product kernel
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -11,6 +13,9 @@
 #include "ob_flash.h"
 #ifdef FL_K64
 #include "attic/ob_flash64_experiment.h"
+#endif
+#ifdef FL_PP
+#include "attic/ob_flash_pp.h"
 #endif
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -37,11 +42,18 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dk, k.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dv, v.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemset(d_o, 0, 2 * n));
-#ifdef FL_K64
+#if defined(FL_PP)
+#define FL_KERNEL ob_flash_pp_kernel<D>
+#define FL_THREADS OB_FLPP_THREADS
+    const int nmb = (S + OB_FLPP_BM - 1) / OB_FLPP_BM;
+    const int dyn0 = OB_FLPP_LDS;
+#elif defined(FL_K64)
+#define FL_THREADS OB_FL_THREADS
 #define FL_KERNEL ob_flash_fwd64_kernel<D>
     const int nmb = (S + OB_FL64_BM - 1) / OB_FL64_BM;
     const int dyn0 = OB_FL64_LDS;
 #else
+#define FL_THREADS OB_FL_THREADS
 #define FL_KERNEL ob_flash_fwd_kernel<D>
     const int nmb = (S + OB_FL_BM - 1) / OB_FL_BM;
     const int dyn0 = 0;
@@ -49,7 +61,7 @@ int main(int argc, char **argv)
     ObFlashArgs a = {dq, dk, dv, d_o, nullptr, S, H, H, S, 0, 1.4426950408889634f / sqrtf((float)D), nmb};
 #ifdef OB_FL_TRACE
     unsigned long long *dtr;
-    const size_t ntr = 2 * (OB_FL_THREADS / 64) * 66 * 8;
+    const size_t ntr = 2 * (FL_THREADS / 64) * 66 * 8;
     CK(hipMalloc(&dtr, 8 * ntr)); CK(hipMemset(dtr, 0, 8 * ntr));
     a.trace = dtr;
 #endif
@@ -58,10 +70,10 @@ int main(int argc, char **argv)
     if (dyn) CK(hipFuncSetAttribute((const void *)FL_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(OB_FL_THREADS), dyn, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(FL_THREADS), dyn, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(OB_FL_THREADS), dyn, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((FL_KERNEL), grid, dim3(FL_THREADS), dyn, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double flop = 4.0 * B * H * (double)S * S * D / 2;
@@ -94,7 +106,12 @@ int main(int argc, char **argv)
 #ifdef OB_FL_TRACE
     std::vector<unsigned long long> tr(ntr);
     CK(hipMemcpy(tr.data(), dtr, 8 * ntr, hipMemcpyDeviceToHost));
-    const int NW = OB_FL_THREADS / 64;
+    const int NW = FL_THREADS / 64;
+    for (int slot = 0; slot < 2; ++slot) {
+        printf("workgroup slot %d: SIMD of waves 0 .. %d:", slot, NW - 1);
+        for (int w = 0; w < NW; ++w) printf(" %llu", (tr[((size_t)slot * NW + w) * 66 * 8 + 65 * 8 + 4] >> 4) & 3);
+        printf("\n");
+    }
     for (int slot = 0; slot < 2; ++slot)
         for (int w = 0; w < NW; w += NW - 1) {
             printf("trace: workgroup slot %d wave %d -- per key block, cycles since the block's first stamp\n", slot, w);
