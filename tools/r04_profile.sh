@@ -27,6 +27,8 @@ timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 echo "rc7=$?"; python $R/tools/pmc_summary.py /tmp/p_at | grep "flash" > $O/pmc_attention.txt
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/p_at2 -- python $R/tools/attn_probe.py > /dev/null 2>> $O/attn_pmc.err
 echo "rc8=$?"; python $R/tools/pmc_summary.py /tmp/p_at2 | grep "flash" >> $O/pmc_attention.txt
+timeout 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d /tmp/p_at3 -- python $R/tools/attn_probe.py > /dev/null 2>> $O/attn_pmc.err
+echo "rc9=$?"; python $R/tools/pmc_summary.py /tmp/p_at3 | grep "flash" >> $O/pmc_attention.txt
 fi
 cd $R
 timeout 100 python tools/decode_kernels.py > $O/decode_insitu.txt 2>&1
