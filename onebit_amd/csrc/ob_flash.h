@@ -38,7 +38,8 @@
 // rearrangements meant to force the overlap were built, are correct, and measured SLOWER; they are kept under tools/attic with
 // their numbers: one wave per SIMD with 64 queries per wave and hand-interleaved softmax (565; ob_flash64_experiment.h), an
 // 8-wave ping-pong where one wave of a SIMD streams MFMAs while its partner does only VALU work (599; ob_flash_pp.h -- its
-// ablations show MFMA-only time + VALU-only time = total time: two waves of a SIMD do not overlap the two kinds of work), and
+// ablations show MFMA-phase time + softmax-phase time ~ total time, although pure MFMA and VALU streams of two waves do overlap
+// on this SIMD: tools/pipe_overlap_probe.hip, profiles/r04_pipe_overlap_probe.txt), and
 // this kernel with the two query tiles of a wave taken in turn, one tile's exponentials interleaved with the other's MFMAs
 // (577; ob_flash_split_experiment.h).
 #pragma once

@@ -1,7 +1,11 @@
 // EXPERIMENT (round 4), not part of the product.  RESULT: correct, 599 TFLOP/s (612 with the VALU phase at raised priority) against
 // the product kernel's 645 -- and the ablations say why: with the softmax arithmetic removed the kernel takes 0.218 ms, with the
-// MFMAs removed 0.257 ms, with both 0.463 ms: a wave streaming MFMAs and a wave doing VALU work on the SAME SIMD do not overlap at
-// all.  (HW_ID confirms waves w and w + 4 share a SIMD.)  Built with -DFL_PP in tools/flash_lab.hip.
+// MFMAs removed 0.257 ms, with both 0.463 ms: the MFMA phase of one wave and the softmax phase of its SIMD partner hardly overlap
+// (HW_ID confirms waves w and w + 4 share a SIMD).  It is not the LDS traffic alone: with every LDS access removed (-DOB_FL_ABL=24,
+// 25, 28) the MFMA phases take 0.147 ms, the softmax phases 0.207 ms and both 0.316 ms.  Pure MFMA and VALU streams of two waves DO
+// overlap on this SIMD (tools/pipe_overlap_probe.hip: the MFMA wave keeps its rate, the VALU wave loses 15-24 %), so what serialises
+// the real phases (dependent VALU chains, cross-lane swaps, the two barriers per block) is the open question.
+// Built with -DFL_PP in tools/flash_lab.hip.
 //
 // Causal prefill attention, head dimension 128: the arithmetic and operand layouts of ob_flash.h (read its header first), with the
 // work of a CU arranged so that its matrix pipes and its VALUs are busy at the SAME time by construction instead of by chance.
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
         const uint32_t kbuf = k_base(lane_m) + (k % NB) * (TILE * 2);
         ob_half8 kf[4 * DK];
         typedef __attribute__((address_space(3))) const ob_half8 ob_lds_half8;
-        auto read_k = [&](int i) { kf[i] = *(ob_lds_half8 *)(ob_lds_char *)(size_t)((kbuf ^ ((i % DK) << 6)) + 16 * (i / DK) * D * 2); };
+        auto read_k = [&](int i) { if (!(OB_FL_ABL & 8)) kf[i] = *(ob_lds_half8 *)(ob_lds_char *)(size_t)((kbuf ^ ((i % DK) << 6)) + 16 * (i / DK) * D * 2); else kf[i] = qf[0][i % DK]; };
         if (do_s) {                                     // in flight underneath the output MFMAs
 #pragma unroll
             for (int i = 0; i < KP; ++i) read_k(i);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
             for (int j = 0; j < VP; ++j) vf[j] = vpre[j];
 #pragma unroll
             for (int j = 0; j < 2 * DT; ++j) {
-                if (j + VP < 2 * DT) vf[j + VP] = read_v(Vb, j + VP);
+                if (j + VP < 2 * DT) vf[j + VP] = (OB_FL_ABL & 8) ? qf[1][j % DK] : read_v(Vb, j + VP);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) acc_o[j % DT][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[j], pb[qt][j / DT], acc_o[j % DT][qt], 0, 0, 0);
                 if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
@@ -189,10 +193,12 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
     };
     // ---- V(k): online softmax of block k (ob_flash.h: the running maximum moves only when a tile exceeds it by more than 2^THR)
     auto v_phase = [&](const int k) {
+        if (!(OB_FL_ABL & 16)) {
         store_k(k + 2);                                 // (blocks past the last one: zeros, never read)
         store_v(k + 1);
         load_k(k + 3);
         load_v(k + 2);
+        }
         if ((OB_FL_ABL & 1) || !is_active(k)) return;
         const int k0 = k * OB_FL_BN;
         const bool diag = k0 + OB_FL_BN - 1 > wave_first_q || k0 + OB_FL_BN > L;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
         }
         const uint32_t Vn = v_base(lane_now()) + (k % NB) * (TILE * 2);
 #pragma unroll
-        for (int j = 0; j < VP; ++j) vpre[j] = read_v(Vn, j);      // (V(k): in LDS since the V(k - 1) phases)
+        for (int j = 0; j < VP; ++j) vpre[j] = (OB_FL_ABL & 24) ? qf[0][j % DK] : read_v(Vn, j);      // (V(k): in LDS since the V(k - 1) phases)
     };
 
     load_k(0); load_v(0);

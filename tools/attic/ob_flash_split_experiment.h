@@ -5,10 +5,8 @@
 //   C  output(q0) + exponentials(q1) D  output(q1)
 // The generated code is exactly that (per step: MFMA, fragment read 4 steps ahead, 3-4 VALU), correct at every shape flash_lab
 // checks -- and SLOWER: 577 TFLOP/s against 645 for the plain body at 8 x 2048 x 32 x 128.  K and V fragments are read once per tile
-// (96 LDS reads per block instead of 48) and a SIMD with two resident waves turned out to be bound by the instructions it
-// ISSUES, not by which pipe they go to (see also ob_flash_pp.h here: an 8-wave ping-pong arrangement where one wave of a SIMD
-// does nothing but MFMAs while its partner does nothing but VALU work -- MFMA-only time 0.218 ms + VALU-only time 0.257 ms
-// = 0.463 ms measured for both together).
+// (96 LDS reads per block instead of 48), and with two such waves on a SIMD its issue port is the limit (tools/pipe_overlap_probe.hip,
+// mv2: two interleaved MFMA + VALU waves take twice as long as one; an MFMA costs the port about 8 cycles, a VALU op 2.75).
 // To try it again: paste `helpers` before the kernel template and `body` before `const int nfull` in ob_flash_fwd_kernel, and call
 // block_main(kb) for kb < nfull.
 #if 0
