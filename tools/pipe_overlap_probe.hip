@@ -61,19 +61,45 @@ __device__ __forceinline__ void stream_mv(St &s)
                  : "v"(s.a), "v"(s.b), "v"(s.x), "v"(s.y));
 }
 
+// MFMA stream fed from LDS the way the attention kernel's score product is: one ds_read_b128 per two MFMAs, requested AHEAD fragments
+// before its use (a ring of 8 fragment registers), counted waits.  MODE 5: AHEAD = 4, MODE 6: AHEAD = 7, MODE 7: the reads only.
+template <int AHEAD, bool WITH_MFMA>
+__device__ __forceinline__ void stream_mr(St &s, half8 (&kf)[8], unsigned lds_addr)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[(i + AHEAD) & 7]) : "v"(lds_addr), "n"(((i + AHEAD) & 7) * 1024));
+        if (AHEAD == 4) asm volatile("s_waitcnt lgkmcnt(4)");
+        else asm volatile("s_waitcnt lgkmcnt(7)");
+        if (WITH_MFMA) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s.c[(2 * i) & 7]) : "v"(kf[i & 7]), "v"(s.b));
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s.c[(2 * i + 1) & 7]) : "v"(kf[i & 7]), "v"(s.b));
+        }
+    }
+}
+
 // mode: 0 M, 1 V, 2 E, 3 P, 4 MV (same wave); group B (waves 4-7 of a 512-thread workgroup) runs MB.  One loop per group and
 // compile-time modes: a run-time choice inside the loop costs ~60 register copies per iteration at the merge points.
 template <int MODE>
 __device__ __forceinline__ unsigned long long run(St &s, int R)
 {
+    half8 kf[8];
+    for (int i = 0; i < 8; ++i) kf[i] = s.a;
+    const unsigned lds_addr = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 8192;
+    if (MODE >= 5) for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(lds_addr), "n"(i * 1024));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < R; ++r) {
         if (MODE == 0) stream_m(s);
         else if (MODE == 1) stream_v(s);
         else if (MODE == 2) stream_e(s);
         else if (MODE == 3) stream_p(s);
-        else stream_mv(s);
+        else if (MODE == 4) stream_mv(s);
+        else if (MODE == 5) stream_mr<4, true>(s, kf, lds_addr);
+        else if (MODE == 6) stream_mr<7, true>(s, kf, lds_addr);
+        else stream_mr<4, false>(s, kf, lds_addr);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    if (MODE >= 5) for (int i = 0; i < 8; ++i) s.f[i] += (float)kf[i][0];
     asm volatile("s_nop 15\n\ts_nop 15");
     return __builtin_amdgcn_s_memtime() - t0;
 }
@@ -113,7 +139,13 @@ int main()
         {"e+m  two waves/SIMD, waves 0-3 v_exp stream, waves 4-7 MFMA stream", 512, probe<2, 0>},
         {"m+p  two waves/SIMD, waves 0-3 MFMA stream, waves 4-7 v_pk_fma stream", 512, probe<0, 3>},
         {"mv+v two waves/SIMD, waves 0-3 interleaved, waves 4-7 VALU stream", 512, probe<4, 1>},
-        {"mv2  two waves/SIMD, both interleaved streams", 512, probe<4, 4>}};
+        {"mv2  two waves/SIMD, both interleaved streams", 512, probe<4, 4>},
+        {"mr1  one wave/SIMD, 16 MFMA + 8 ds_read_b128, fragments 4 ahead", 256, probe<5, 5>},
+        {"mr1' one wave/SIMD, 16 MFMA + 8 ds_read_b128, fragments 7 ahead", 256, probe<6, 6>},
+        {"r1   one wave/SIMD, the 8 ds_read_b128 alone (4 ahead)", 256, probe<7, 7>},
+        {"mr2  two waves/SIMD, both 16 MFMA + 8 ds_read_b128 (4 ahead)", 512, probe<5, 5>},
+        {"mr+v two waves/SIMD, waves 0-3 MFMA + reads, waves 4-7 VALU stream", 512, probe<5, 1>},
+        {"mr+mv two waves/SIMD, waves 0-3 MFMA + reads, waves 4-7 interleaved MFMA + VALU", 512, probe<5, 4>}};
     printf("cycles per iteration (first wave of waves 0-3 | of waves 4-7); an iteration = 16 MFMAs (256 pipe cycles) and / or 64 VALU ops\n");
     for (auto &x : v) {
         hipMemset(d, 0, 64);
