@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned long long run(St &s, int R)
     return __builtin_amdgcn_s_memtime() - t0;
 }
 template <int MA, int MB>
-__global__ __launch_bounds__(512) void probe(unsigned long long *out, int R)
+__global__ __launch_bounds__(1024) void probe(unsigned long long *out, int R)
 {
     extern __shared__ char pad[];       // the launch asks for > half the LDS: one workgroup per CU
     St s;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(512) void probe(unsigned long long *out, int R)
     float acc = 0.f;
     for (int i = 0; i < 8; ++i) acc += s.c[i][0] + s.f[i] + s.p[i][0];
     if (acc == 12345.678f) out[1023] = 1;     // keeps the results alive
-    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[wave] = dt;
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[wave] = dt;     // (waves 8-15 of a 1024-thread workgroup run MB too)
 }
 typedef void (*probe_fn)(unsigned long long *, int);
 
 int main()
 {
-    unsigned long long *d, h[8];
+    unsigned long long *d, h[16];
     hipMalloc(&d, 8192);
     const int R = 40000;
     struct { const char *name; int threads; probe_fn fn; } v[] = {
@@ -140,6 +140,11 @@ int main()
         {"m+p  two waves/SIMD, waves 0-3 MFMA stream, waves 4-7 v_pk_fma stream", 512, probe<0, 3>},
         {"mv+v two waves/SIMD, waves 0-3 interleaved, waves 4-7 VALU stream", 512, probe<4, 1>},
         {"mv2  two waves/SIMD, both interleaved streams", 512, probe<4, 4>},
+        {"v4   FOUR waves/SIMD, all the VALU stream (slowest of waves 0-3 | 4-7 shown)", 1024, probe<1, 1>},
+        {"e4   FOUR waves/SIMD, all the v_exp stream", 1024, probe<2, 2>},
+        {"p4   FOUR waves/SIMD, all the v_pk_fma stream", 1024, probe<3, 3>},
+        {"p2   two waves/SIMD, both the v_pk_fma stream", 512, probe<3, 3>},
+        {"e2   two waves/SIMD, both the v_exp stream", 512, probe<2, 2>},
         {"mr1  one wave/SIMD, 16 MFMA + 8 ds_read_b128, fragments 4 ahead", 256, probe<5, 5>},
         {"mr1' one wave/SIMD, 16 MFMA + 8 ds_read_b128, fragments 7 ahead", 256, probe<6, 6>},
         {"r1   one wave/SIMD, the 8 ds_read_b128 alone (4 ahead)", 256, probe<7, 7>},
@@ -148,7 +153,7 @@ int main()
         {"mr+mv two waves/SIMD, waves 0-3 MFMA + reads, waves 4-7 interleaved MFMA + VALU", 512, probe<5, 4>}};
     printf("cycles per iteration (first wave of waves 0-3 | of waves 4-7); an iteration = 16 MFMAs (256 pipe cycles) and / or 64 VALU ops\n");
     for (auto &x : v) {
-        hipMemset(d, 0, 64);
+        hipMemset(d, 0, 128);
         hipFuncSetAttribute((const void *)x.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 100000);
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(x.fn, dim3(256), dim3(x.threads), 100000, 0, d, R);
         hipEvent_t e0, e1;
@@ -157,8 +162,10 @@ int main()
         hipLaunchKernelGGL(x.fn, dim3(256), dim3(x.threads), 100000, 0, d, R);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
-        const unsigned long long tmax = x.threads == 256 ? h[0] : (h[0] > h[4] ? h[0] : h[4]);
+        hipMemcpy(h, d, 128, hipMemcpyDeviceToHost);
+        unsigned long long tmax = 0;
+        for (int w = 0; w < x.threads / 64; ++w) tmax = h[w] > tmax ? h[w] : tmax;
+        if (x.threads == 1024) { h[0] = 0; for (int w = 0; w < 16; ++w) h[0] = h[w] > h[0] ? h[w] : h[0]; h[4] = h[0]; }
         if (x.threads == 256) printf("%-72s %7.1f            ", x.name, (double)h[0] / R);
         else printf("%-72s %7.1f | %7.1f  ", x.name, (double)h[0] / R, (double)h[4] / R);
         printf("  kernel %.2f ms: %.0f s_memtime ticks per microsecond\n", ms, tmax / (ms * 1e3));
