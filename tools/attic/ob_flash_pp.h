@@ -5,6 +5,7 @@
 // 25, 28) the MFMA phases take 0.147 ms, the softmax phases 0.207 ms and both 0.316 ms.  Pure MFMA and VALU streams of two waves DO
 // overlap on this SIMD (tools/pipe_overlap_probe.hip: the MFMA wave keeps its rate, the VALU wave loses 15-24 %), so what serialises
 // the real phases (dependent VALU chains, cross-lane swaps, the two barriers per block) is the open question.
+// Without the half-period offset (-DOB_FLPP_LOCKSTEP=1: both waves of a SIMD always in the same phase) it is slower still: 572 against 606.
 // Built with -DFL_PP in tools/flash_lab.hip.
 //
 // Causal prefill attention, head dimension 128: the arithmetic and operand layouts of ob_flash.h (read its header first), with the
@@ -35,6 +36,9 @@
 
 #ifndef OB_FLPP_PRIO
 #define OB_FLPP_PRIO 0         // 1: the VALU phase runs at raised priority, 2: the MFMA phase
+#endif
+#ifndef OB_FLPP_LOCKSTEP
+#define OB_FLPP_LOCKSTEP 0     // 1: no offset between the groups -- both waves of a SIMD are in the same phase
 #endif
 #define OB_FLPP_BM 256
 #define OB_FLPP_NB 3
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
     load_k(2); load_v(1);
     __syncthreads();
     OB_FL_TP(1);
-    if (grp == 1) __syncthreads();                      // group 1 runs half a period behind
+    if (!OB_FLPP_LOCKSTEP && grp == 1) __syncthreads(); // group 1 runs half a period behind
     for (int kb = 0; kb <= nkb; ++kb) {
         OB_FL_T(0);
 #if OB_FLPP_PRIO == 2
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(OB_FLPP_THREADS) void ob_flash_pp_kernel(const ObFl
         __syncthreads();
         OB_FL_T(4);
     }
-    if (grp == 0) __syncthreads();
+    if (!OB_FLPP_LOCKSTEP && grp == 0) __syncthreads();
     OB_FL_TP(2);
 
     // ---- normalise and write: lane holds d = 16 dt + 4 g .. + 3 of query lr of each tile
