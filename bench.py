@@ -76,6 +76,7 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-serve", action="store_true", help="skip the continuous-batching (config 5) field")
+    ap.add_argument("--no-train", action="store_true", help="skip the train-mode layer field (forward + backward of BitLinear at a 7B MLP shape)")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-caller field (perplexity windows + ragged loglikelihood batch)")
     ap.add_argument("--no-k-sharded-decode", action="store_true",
                     help="skip BASELINE config 4 (LLaMA-13B shapes, module-path decode with every 1-bit layer K-sharded "
@@ -606,6 +607,39 @@ def measure_cpu_baseline(cfg):
     return out
 
 
+def measure_train_layer(dev, T=4096, K=4096, N=11008, iters=5):
+    """forward + backward of the train-mode BitLinear (latent weights, SignSTE) at a 7B MLP shape, fp16:
+    three GEMMs of 2 T K N flops (z = a S^T, ga = gz S, gS = gz^T a) + the LayerNorm / column-sum kernels around them."""
+    import torch
+    from onebit_amd.train import BitLinear
+    torch.manual_seed(0)
+    m = BitLinear(K, N, dtype=torch.float16).to(dev)
+    with torch.no_grad():
+        m.weight.normal_(0, 0.02)
+        m.weight_scale.uniform_(0.05, 0.15)
+        m.input_factor.uniform_(0.05, 0.15)
+    x = torch.randn(T, K, device=dev, dtype=torch.float16, requires_grad=True)
+    gy = torch.randn(T, N, device=dev, dtype=torch.float16)
+
+    def step():
+        m(x).backward(gy)
+        m.zero_grad(set_to_none=True)
+        x.grad = None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    return {"layer": "%d->%d" % (K, N), "tokens": T, "dtype": "f16", "ms_forward_backward": round(ms, 3), "TFLOPs": round(6.0 * T * K * N / ms / 1e9, 1),
+            "flops": "3 GEMMs x 2 T K N", "kernels": "ob_tgemm128_f16_kernel (sign / x*h applied while staging, STE in the epilogue) + LayerNorm forward / backward + column sums",
+            "per": "GPU", "data": "synthetic"}
+
+
 class Hooks:
     """Everything main() touches besides its own control flow (which ranks run what, where the collectives and
     barriers sit, how the JSON line is assembled).  The world-2 gloo test (tests/test_bench_cpu.py) substitutes CPU
@@ -647,6 +681,7 @@ class Hooks:
     measure_k_sharded_decode = staticmethod(measure_k_sharded_decode)
     measure_cpu_baseline = staticmethod(measure_cpu_baseline)
     measure_eval = staticmethod(measure_eval)
+    measure_train_layer = staticmethod(measure_train_layer)
 
 
 def main(argv=None, hooks=None):
@@ -747,6 +782,12 @@ def main(argv=None, hooks=None):
             evalf = hk.measure_eval(model, dev)
         except Exception as e:
             evalf = {"error": "%s: %s" % (type(e).__name__, e)}
+    trainf = None
+    if not args.no_train and rank == 0:         # the train-mode layer
+        try:
+            trainf = hk.measure_train_layer(dev)
+        except Exception as e:
+            trainf = {"error": "%s: %s" % (type(e).__name__, e)}
     pmodel_tp = None
     if not args.no_prefill:
         try:
@@ -815,6 +856,8 @@ def main(argv=None, hooks=None):
             out["prefill_model_tp"] = pmodel_tp
         if evalf is not None:
             out["eval_ppl"] = evalf
+        if trainf is not None:
+            out["train_layer"] = trainf
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -1574,6 +1574,16 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
 template <typename TI, bool RCA, bool RCB, int TXA, int TXB, int EPI>
 static void ob_launch_tgemm(const ObTGemmArgs &a, hipStream_t s)
 {
+    if constexpr (std::is_same<TI, _Float16>::value) {      // gfx950 tiling for fp16 (ob_train.h); fp32 keeps the 64 x 64 form
+        static const bool legacy = getenv("OB_TRAIN_GEMM64") != nullptr;
+        if (!legacy) {
+            const dim3 grid((unsigned)((a.N + OB_TG2_B - 1) / OB_TG2_B), (unsigned)((a.M + OB_TG2_B - 1) / OB_TG2_B));
+            static bool attr_set[OB_MAX_DEVICES] = {};
+            ob_set_max_lds_once(ob_tgemm128_f16_kernel<RCA, RCB, TXA, TXB, EPI>, attr_set, OB_TG2_LDS);
+            hipLaunchKernelGGL((ob_tgemm128_f16_kernel<RCA, RCB, TXA, TXB, EPI>), grid, dim3(OB_TG_THREADS), OB_TG2_LDS, s, a);
+            return;
+        }
+    }
     const dim3 grid((unsigned)((a.N + OB_TG_BN - 1) / OB_TG_BN), (unsigned)((a.M + OB_TG_BM - 1) / OB_TG_BM));
     hipLaunchKernelGGL((ob_tgemm_kernel<TI, RCA, RCB, TXA, TXB, EPI>), grid, dim3(OB_TG_THREADS), 0, s, a);
 }
@@ -1584,7 +1594,8 @@ extern "C" size_t onebit_train_workspace_bytes(int64_t T, int64_t K, int64_t N, 
 {
     if (T <= 0 || K <= 0 || N <= 0) return 0;
     const size_t sz = dtype == ONEBIT_F32 ? 4 : 2;
-    return ob_train_align((size_t)T * N * sz) + ob_train_align((size_t)T * K * sz) + ob_train_align((size_t)T * 2 * sizeof(float));
+    return ob_train_align((size_t)T * N * sz) + ob_train_align((size_t)T * K * sz) + ob_train_align((size_t)T * 2 * sizeof(float)) +
+           ob_train_align((size_t)OB_TC_SLICES * (2 * (size_t)N > (size_t)K ? 2 * (size_t)N : (size_t)K) * sizeof(float));     // column-sum partials
 }
 
 static int ob_train_check(const char *what, int64_t T, int64_t K, int64_t N, int dtype)
@@ -1633,12 +1644,14 @@ static int ob_train_backward_t(const void *gy, const void *x, const void *w, con
     TI *gz = (TI *)ws;
     TI *ga = (TI *)(ws + ob_train_align((size_t)T * N * sizeof(TI)));
     float *rowc = (float *)(ws + ob_train_align((size_t)T * N * sizeof(TI)) + ob_train_align((size_t)T * K * sizeof(TI)));
+    float *part = (float *)((char *)rowc + ob_train_align((size_t)T * 2 * sizeof(float)));     // [OB_TC_SLICES][2 N | K] column-sum partials
     int rc;
     // 1. through the LayerNorm and * g: gz [T, N]; column sums gg, gbias
     hipLaunchKernelGGL((ob_train_ln_bwd_kernel<TI>), dim3((unsigned)T), dim3(256), 0, s, (const TI *)gy, (const TI *)z, (const TI *)g, stats, gz, rowc, (int)N);
     if ((rc = ob_launch_status("train_backward(layernorm)"))) return rc;
-    hipLaunchKernelGGL((ob_train_cols_ln_kernel<TI>), dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, (const TI *)gy, (const TI *)z, (const TI *)g, stats,
-                       (const float *)rowc, (TI *)gg, (TI *)gbias, (int)T, (int)N);
+    hipLaunchKernelGGL((ob_train_cols_ln_kernel<TI>), dim3((unsigned)((N + 63) / 64), OB_TC_SLICES), dim3(256), 0, s, (const TI *)gy, (const TI *)z, (const TI *)g, stats,
+                       (const float *)rowc, part, (int)T, (int)N);
+    hipLaunchKernelGGL((ob_train_cols_finish_kernel<TI, 2>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const float *)part, (TI *)gg, (TI *)gbias, (int)N);
     if ((rc = ob_launch_status("train_backward(gg)"))) return rc;
     // 2. ga [T, K] = gz . sign(W);  gx = ga * h;  gh = sum_t ga * x
     {
@@ -1648,7 +1661,8 @@ static int ob_train_backward_t(const void *gy, const void *x, const void *w, con
         a.C = ga; a.C2 = gx; a.vc = h; a.ldc = K; a.M = (int)T; a.N = (int)K; a.R = (int)N;
         ob_launch_tgemm<TI, true, false, OB_TX_NONE, OB_TX_SIGN, OB_TE_GX>(a, s);
         if ((rc = ob_launch_status("train_backward(grad input)"))) return rc;
-        hipLaunchKernelGGL((ob_train_cols_gh_kernel<TI>), dim3((unsigned)((K + 63) / 64)), dim3(256), 0, s, (const TI *)ga, (const TI *)x, (TI *)gh, (int)T, (int)K);
+        hipLaunchKernelGGL((ob_train_cols_gh_kernel<TI>), dim3((unsigned)((K + 63) / 64), OB_TC_SLICES), dim3(256), 0, s, (const TI *)ga, (const TI *)x, part, (int)T, (int)K);
+        hipLaunchKernelGGL((ob_train_cols_finish_kernel<TI, 1>), dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, (const float *)part, (TI *)gh, (TI *)nullptr, (int)K);
         if ((rc = ob_launch_status("train_backward(gh)"))) return rc;
     }
     // 3. gW [N, K] = (gz^T . (x * h)) * (1.001 - tanh(W)^2)

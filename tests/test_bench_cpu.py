@@ -134,6 +134,11 @@ def _main_worker(rank, world, port, q):
             return {"perplexity": {}}
 
         @staticmethod
+        def measure_train_layer(dev):
+            assert dist.get_rank() == 0
+            return {"TFLOPs": 1.0}
+
+        @staticmethod
         def measure_prefill_model_tp(model, dev, world_, rank_):
             collective("prefill_model_tp")
             return {"tp_degree": world_}
@@ -187,6 +192,6 @@ def test_main_control_flow_two_ranks_gloo():
     assert line["metric"] == "decode_tokens_per_sec" and line["value"] > 0
     assert line["cpu_baseline"] is not None and line["cpu_baseline"]["kind"] == "port"        # emitted at every N
     assert line["roofline"]["bound"] == "hbm"
-    for k in ("prefill_k_sharded", "decode_k_sharded", "continuous_batch", "prefill_model", "prefill_model_tp", "eval_ppl"):
+    for k in ("prefill_k_sharded", "decode_k_sharded", "continuous_batch", "prefill_model", "prefill_model_tp", "eval_ppl", "train_layer"):
         assert k in line, k
     assert line["decode_k_sharded"]["k_shards"] == 2 and line["decode_k_sharded"]["model"] == "LLaMA-13B shapes"

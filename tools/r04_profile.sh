@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 echo "rc1=$?"; cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv; tail -2 $O/bench_profiled.err
 # 2. FETCH_SIZE pass (own run: counters only beside the kernel trace)
-D="--steps 8 --warmup 2 --no-cpu-baseline --no-prefill --no-serve --no-roofline --no-k-sharded-decode --no-eval"
+D="--steps 8 --warmup 2 --no-cpu-baseline --no-prefill --no-serve --no-roofline --no-k-sharded-decode --no-eval --no-train"
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python $R/bench.py $D > /dev/null 2> $O/fetch.err
 echo "rc2=$?"; python $R/tools/pmc_summary.py /tmp/p_fetch > $O/pmc_FETCH_SIZE.txt; tail -1 $O/fetch.err
 # 3. issue / wait counters of the decode kernels
