@@ -19,8 +19,12 @@ LayerNorm-terminated projections:
   short   12-token prompt: prefill logits + 2 incremental decode steps, fp16 and fp32
   batch   8 sequences x 6 prompt tokens in one batched reference call + 2 batched decode steps, fp16 and fp32
 
-Output: tests/golden/model_wide_c.npz / model_wide_d.npz (data only).  Usage (from the repo root):
-  PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/transformers/src:. python tests/golden/gen_goldens_model_wide.py [c|d] [parts...]
+Config "e" (round 4) = LLaMA-13B layer widths (hidden 5120, intermediate 13824, 40 heads of 128; BASELINE configs 4 and 5), 2 layers,
+seed 13: 12-token prompt + 3 decode steps, 8 sequences batched + 2 batched steps, fp16 and fp32 -- pins the 13B launch geometries
+(one projection per workgroup with 80 / 124 workgroups per projection) and the K-sharded module path to the reference.
+
+Output: tests/golden/model_wide_c.npz / model_wide_d.npz / model_wide_e.npz (data only).  Usage (from the repo root):
+  PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/transformers/src:. python tests/golden/gen_goldens_model_wide.py [c|d|e] [parts...]
 """
 import importlib.metadata as md
 import os
@@ -52,6 +56,9 @@ CONFIGS = {
     "d": dict(kw=dict(vocab_size=512, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
                       num_attention_heads=32, max_position_embeddings=256),
               seed=11, parts=["short", "batch"], steps=2, batch=(8, 6), batch_steps=2),
+    "e": dict(kw=dict(vocab_size=512, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                      num_attention_heads=40, max_position_embeddings=256),
+              seed=13, parts=["short", "batch"], steps=3, batch=(8, 6), batch_steps=2),
 }
 LONG = 4096
 

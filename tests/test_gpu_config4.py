@@ -85,7 +85,9 @@ def test_shard_model_k_world1_13b_width():
     """`shard_model_k` (what bench.py's decode_k_sharded runs on every rank) on a 2-layer model of 13B
     layer widths at world 1: prefill + 3 decode steps equal the unsharded module path (the same kernels
     behind a different epilogue entry point: u may differ by an ulp where fp32 partials round differently
-    from the fused kernel's sum, hence the logit tolerance of the other model tests)."""
+    from the fused kernel's sum, hence the logit tolerance of the other model tests).  The same sharded model is held to the
+    REFERENCE's logits at these widths in tests/test_gpu_model_13b_width.py (round 4); this test keeps the two routes of the build
+    next to each other."""
     from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
     from onebit_amd.sharded import KShardedBitLinear, shard_model_k
     dev = torch.device("cuda:0")
