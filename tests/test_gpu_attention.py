@@ -66,6 +66,28 @@ def test_large_scores_and_peaked_softmax():
     assert float((o.float() - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("per_block_log2", [5.0, 9.0, 0.5])
+def test_slowly_and_quickly_rising_maximum(per_block_log2):
+    """The kernel moves its running maximum only when a 64-key tile exceeds it by more than 2^8 (csrc/ob_flash.h): scores that rise
+    by 5 log2 units per key block alternate between the deferred and the rescaling branch, 9 per block rescales every block, 0.5
+    defers for 16 blocks in a row -- each against the fp32 arithmetic, with V chosen so that a missed rescale shows."""
+    from onebit_amd.llama import hip_attention_prefill
+    B, S, H, D = 1, 1024, 2, 128
+    g = torch.Generator().manual_seed(11)
+    q = (0.05 * torch.randn(B, S, H, D, generator=g)).half()
+    kc = (0.05 * torch.randn(B, H, S, D, generator=g)).half()
+    slope = per_block_log2 / 64.0 / 1.4426950408889634 * math.sqrt(D)          # raw score units per key
+    q[..., 0] = 4.0
+    kc[..., 0] = (slope / 4.0) * torch.arange(S, dtype=torch.float32)[None, None, :]
+    vc = torch.randn(B, H, S, D, generator=g).half()
+    vc[..., 1] = torch.arange(S, dtype=torch.float32)[None, None, :] / 64.0          # a column that tracks WHICH keys carried the mass
+    q, kc, vc = q.to(DEV), kc.to(DEV), vc.to(DEV)
+    o = hip_attention_prefill(q, kc, vc, 0)
+    ref = _ref(q, kc, vc, 0)
+    assert torch.isfinite(o).all()
+    assert float((o.float() - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+
+
 def test_config3_shape_matches_sdpa_and_is_deterministic():
     """BASELINE config 3 attention shape (8 x 2048 tokens, 32 heads of 128): against torch's fused attention on the same
     inputs, bit-identical on repetition."""
