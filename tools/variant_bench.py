@@ -39,7 +39,7 @@ def run(args):
         env = dict(os.environ)
         if lib:
             env["ONEBIT_LIB"] = lib
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "128", "--warmup", "16", "--no-cpu-baseline", "--no-k-sharded-decode"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "128", "--warmup", "16", "--no-cpu-baseline", "--no-k-sharded-decode", "--no-eval", "--no-train"]
         if "serve" not in extra: cmd.append("--no-serve")
         if "prefill" not in extra: cmd.append("--no-prefill")
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
