@@ -317,7 +317,8 @@ class BatchedDecodeStep:
     """``onebit_decode_step_batched`` bound to a model and B KV-cache slots: one new token for every
     slot per call (skinny 1-bit GEMMs over the [B, hidden] rows, row-wise glue kernels, attention per
     (head, slot)); the caller owns scheduling, lm_head and sampling.  ``caches[l] = (k, v)`` with k, v
-    ``[B, n_kv_heads, max_len, head_dim]`` fp16."""
+    ``[B, n_kv_heads, max_len, head_dim]`` fp16 on the model's device -- for an fp32 checkpoint build them with
+    ``fp16_view(model).new_cache(B, max_len)`` (the model's own ``new_cache`` would be fp32 and is refused)."""
 
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
                  keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True, chains: int = 0):
@@ -333,11 +334,19 @@ class BatchedDecodeStep:
         self.model, self.cfg, self.dev, self.batch = model, cfg, p.device, batch
         self.lib = _lib.load()
         dev, f16 = self.dev, torch.float16
+        f16_t = torch.float16
         H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
         shape = (batch, cfg.num_key_value_heads, max_len, D)
         for i, (kc, vc) in enumerate(caches):
             if tuple(kc.shape) != shape or tuple(vc.shape) != shape or not kc.is_contiguous() or not vc.is_contiguous():
                 raise ValueError(f"cache {i} must be contiguous {shape}")
+            # the attention kernels read and write the caches as fp16 on the model's device whatever the checkpoint's
+            # dtype: an fp32 model's own new_cache() would be reinterpreted silently (results wrong, nothing out of bounds)
+            if kc.dtype != f16_t or vc.dtype != f16_t:
+                raise ValueError(f"cache {i} must be float16 (got {kc.dtype} / {vc.dtype}): build the caches with "
+                                 "fp16_view(model).new_cache(batch, max_len)")
+            if kc.device != p.device or vc.device != p.device:
+                raise ValueError(f"cache {i} must be on the model's device {p.device}")
         self._model, self._keep = _model_struct(model, caches, max_len)
         z = lambda *n: torch.zeros(*n, dtype=f16, device=dev)
         Hq, Hkv = cfg.num_attention_heads * D, cfg.num_key_value_heads * D

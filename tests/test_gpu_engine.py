@@ -307,6 +307,9 @@ def test_engine_accepts_fp32_checkpoint(golden_dir):
     # the batched step takes the fp32 model the same way
     cache = view.new_cache(2, 16)
     BatchedDecodeStep(m32, cache.layers, 2, 16)
+    # ... and refuses the fp32 model's OWN caches (fp32 storage would be read and written as fp16 by the attention kernels)
+    with pytest.raises(ValueError, match="float16"):
+        BatchedDecodeStep(m32, m32.new_cache(2, 16).layers, 2, 16)
 
 
 def test_engine_bias_checkpoint_names_the_remedy(golden_dir):
