@@ -38,10 +38,9 @@ def _tol(z, name):
     return max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
 
 
-def _check(got, ref16, ref32, tol, what):
-    for dn, ref in (("f16", ref16), ("f32", ref32)):
-        err = float(np.abs(got - ref.reshape(got.shape)).max())
-        assert err <= tol, (what, dn, err, tol)
+def _check(got, ref16, ref32, tol, what, name="logits"):
+    from _parity_log import check
+    check("model_wide_e", name, what, got, ref16, ref32, loose=tol)
 
 
 @pytest.mark.parametrize("route", ["module", "fused+hip", "k-sharded world 1"])
@@ -60,11 +59,11 @@ def test_prefill_and_decode_routes_13b_width(wide13, route):
     toks = torch.from_numpy(z["greedy_f16"]).to(dev)
     cache = model.new_cache(1, 32)
     lg = model(ids, cache).cpu().numpy()
-    _check(lg, z["prefill_logits_f16"], z["prefill_logits_f32"], _tol(z, "prefill_logits"), route)
+    _check(lg, z["prefill_logits_f16"], z["prefill_logits_f32"], _tol(z, "prefill_logits"), route, "prefill_logits")
     assert int(lg[0, -1].argmax()) == int(toks[0, 0])
     n = z["decode_logits_f16"].shape[1]
     dec = np.concatenate([model(toks[:, i:i + 1], cache).cpu().numpy() for i in range(n)], axis=1)
-    _check(dec, z["decode_logits_f16"], z["decode_logits_f32"], _tol(z, "decode_logits"), route + " decode")
+    _check(dec, z["decode_logits_f16"], z["decode_logits_f32"], _tol(z, "decode_logits"), route + " decode", "decode_logits")
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
@@ -83,7 +82,7 @@ def test_decode_engine_13b_width(wide13, use_graph):
         eng.set_state(int(toks[i]), ids.shape[1] + i)            # teacher-forced with the reference's tokens
         eng.step()
         lg = eng.logits().cpu().numpy()
-        _check(lg, z["decode_logits_f16"][0, i], z["decode_logits_f32"][0, i], tol, f"engine step {i}")
+        _check(lg, z["decode_logits_f16"][0, i], z["decode_logits_f32"][0, i], tol, f"DecodeEngine graph={int(use_graph)} step {i}", "decode_logits")
         assert int(lg.argmax()) == int(toks[i + 1])
 
 
@@ -99,7 +98,7 @@ def test_batched_decode_step_13b_width(wide13):
     lg = model(bids, cache)[:, -1].cpu().numpy()
     ref16, ref32 = z["batch_logits_f16"], z["batch_logits_f32"]
     tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
-    assert np.abs(lg - ref16[:, 0]).max() <= tol
+    _check(lg, ref16[:, 0], ref32[:, 0], tol, "module path, batched prefill", "batch_prefill")
     step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True)
     toks = z["batch_greedy_f16"]
     for i in range(ref16.shape[1] - 1):
@@ -108,5 +107,4 @@ def test_batched_decode_step_13b_width(wide13):
         step.launch()
         torch.cuda.synchronize()
         got = step.logits.float().cpu().numpy()
-        assert np.abs(got - ref16[:, 1 + i]).max() <= tol, i
-        assert np.abs(got - ref32[:, 1 + i]).max() <= tol, i
+        _check(got, ref16[:, 1 + i], ref32[:, 1 + i], tol, f"BatchedDecodeStep step {i}", "batch_decode")

@@ -6,9 +6,10 @@ batched + 2 batched decode steps).  Weights regenerate bit-exactly from the seed
 
 This pins error growth through 32 x 7 LayerNorm-terminated 1-bit projections for every route of the build --
 module path, fused prefill route (row kernels + own attention), ``DecodeEngine`` (HIP graph and direct),
-``BatchedDecodeStep`` (one chain and two chains) -- against the reference itself, with the bar of the other model
-tests: ``max(2 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)``.  It replaces the round-1..3 comparison of
-the 32-layer engine with this repo's own module path.
+``BatchedDecodeStep`` (one chain and two chains) -- against the reference itself.  Bar (round 5): 1.25 x the worst error
+measured for the golden over all routes (``tests/_parity_log.py``, ``profiles/r05_model_parity.txt``), never looser than
+rounds 1-4's ``max(2 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)``.  It replaces the round-1..3 comparison
+of the 32-layer engine with this repo's own module path.
 """
 import os
 
@@ -31,19 +32,9 @@ def deep(golden_dir):
     return z, cfg, model.to(torch.device("cuda:0")).eval()
 
 
-def _tol(z, a="prefill_logits"):
-    ref16, ref32 = z[a + "_f16"], z[a + "_f32"]
-    return max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
-
-
-def _check(got, z, name, what):
-    tol = _tol(z, name)
-    for dn in ("f16", "f32"):
-        ref = z[f"{name}_{dn}"]
-        ref = ref if ref.shape == got.shape else ref.reshape(got.shape)
-        err = float(np.abs(got - ref).max())
-        assert err <= tol, (what, dn, err, tol)
-    return tol
+def _check(got, z, name, what, loose=None):
+    from _parity_log import check
+    return check("model_wide_d", name, what, got, z[f"{name}_f16"], z[f"{name}_f32"], loose=loose)
 
 
 @pytest.mark.parametrize("route", ["module", "fused+sdpa", "fused+hip"])
@@ -85,7 +76,9 @@ def test_decode_engine_full_depth(deep, use_graph):
         eng.set_state(int(toks[i]), ids.shape[1] + i)            # teacher-forced with the reference's tokens
         eng.step()
         lg = eng.logits().cpu().numpy()
-        _check(lg, {k: z[k][0, i] for k in ("decode_logits_f16", "decode_logits_f32")}, "decode_logits", f"engine step {i}")
+        from _parity_log import loose_tol
+        _check(lg, {k: z[k][0, i] for k in ("decode_logits_f16", "decode_logits_f32")}, "decode_logits", f"DecodeEngine graph={int(use_graph)} step {i}",
+               loose=loose_tol(z["decode_logits_f16"], z["decode_logits_f32"]))
         assert int(lg.argmax()) == int(toks[i + 1])
 
 
@@ -102,9 +95,10 @@ def test_batched_decode_step_full_depth(deep, chains):
     max_len = 16
     cache = model.new_cache(B, max_len)
     lg = model(bids, cache)[:, -1].cpu().numpy()
+    from _parity_log import check
     ref16, ref32 = z["batch_logits_f16"], z["batch_logits_f32"]
-    tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
-    assert np.abs(lg - ref16[:, 0]).max() <= tol
+    from _parity_log import loose_tol
+    check("model_wide_d", "batch_prefill", "module path, 8 sequences", lg, ref16[:, 0], ref32[:, 0], loose=loose_tol(ref16, ref32))
     step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True, chains=chains)
     toks = z["batch_greedy_f16"]
     got_all = []
@@ -115,9 +109,8 @@ def test_batched_decode_step_full_depth(deep, chains):
         torch.cuda.synchronize()
         got = step.logits.float().cpu().numpy()
         got_all.append(got)
-        err = np.abs(got - ref16[:, 1 + i]).max()
-        assert err <= tol, (i, err, tol)
-        assert np.abs(got - ref32[:, 1 + i]).max() <= tol
+        check("model_wide_d", "batch_decode", f"BatchedDecodeStep chains={chains} step {i}", got, ref16[:, 1 + i], ref32[:, 1 + i],
+              loose=loose_tol(ref16, ref32))
     key = "_batched_depth_logits"
     prev = getattr(test_batched_decode_step_full_depth, key, None)
     if prev is not None:
