@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 7
+#define ONEBIT_ABI_VERSION 8
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -220,6 +220,9 @@ typedef struct onebit_layer {
     const void *input_layernorm_w;            /* fp16 [hidden] */
     const void *post_attention_layernorm_w;   /* fp16 [hidden] */
     void *k_cache, *v_cache;                  /* fp16 [n_kv_heads, max_len, head_dim] */
+    /* ABI 8: projection biases of a checkpoint with config.attention_bias (modeling_bitllama.py:451-454; added after the
+     * projection's LayerNorm, bitnet.py:119-120), fp16 [N] each, or NULL.  q / k / v: all three or none.             */
+    const void *q_bias, *k_bias, *v_bias, *o_bias;
 } onebit_layer_t;
 
 typedef struct onebit_model {
@@ -233,6 +236,9 @@ typedef struct onebit_model {
 } onebit_model_t;
 
 typedef struct onebit_decode_state {
+    /* ABI 8: sizeof(onebit_decode_state_t) as the CALLER compiled it.  The library refuses a state of another size
+     * (ONEBIT_E_ARG) instead of reading appended fields past the end of a struct built against an older header.     */
+    uint64_t struct_size;
     int32_t *token;             /* device: in = token to process, out = greedy next token      */
     int32_t *pos;               /* device: tokens already in the KV cache; incremented         */
     int32_t *out_tokens;        /* device [max_out] or NULL: out_tokens[pos_before] = next     */
@@ -278,6 +284,7 @@ int onebit_decode_step(const onebit_model_t *model, const onebit_decode_state_t 
  * slot (its row is computed but attention and the cache append are skipped).  2 <= B <= 64.
  */
 typedef struct onebit_batch_state {
+    uint64_t struct_size;       /* ABI 8: sizeof(onebit_batch_state_t) as the caller compiled it (checked, see above) */
     int32_t batch;              /* B                                                            */
     const int32_t *tokens;      /* device [B]: token to process per slot                        */
     const int32_t *pos;         /* device [B]: tokens already cached per slot, < 0 = idle       */

@@ -19,7 +19,7 @@ FLAG_SKIP_LN = 1
 FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
 FLAG_PRESCALED = 4
 FLAG_TILE_STATS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
 _i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint

@@ -16,6 +16,8 @@ struct ObBNormArgs {
     const _Float16 *u_prev;       // !EMBED: [B, H] pre-LayerNorm output of the previous projection, or NULL with
     const float *z0, *z1;         //   fp32 split-K partial sums [B, H] of it (u = fp16(fp16(z0 + z1) * g_prev))
     const _Float16 *g_prev;       //   and its weight_scale [H]
+    const _Float16 *bias_prev;    // optional [H]: bias of the projection that produced u_prev (o_proj with config.attention_bias):
+                                  //   r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120, then :912)
     const _Float16 *rms_w;        // [H]
     _Float16 *hres_out;           // [B, H]
     _Float16 *x;                  // [B, H] (may be NULL when only the scaled outputs are wanted)
@@ -89,6 +91,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
             ob_half8 ln;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ln[i] = ob_ln_apply_h(uv[v][i], rstd, nmr);
+            if (A.bias_prev && valid[v])         // (uniform pointer test; batched decode step of a checkpoint with attention_bias)
+                ln = ln + *reinterpret_cast<const ob_half8 *>(A.bias_prev + (v * OB_DEC_THREADS + tid) * 8);
             hv[v] = hv[v] + ln;                  // residual + hidden_states
         }
     }

@@ -63,6 +63,9 @@ struct ObGemvArgs {
     // workgroup barrier.  Buffers hold a multiple of 256 tiles (reads beyond K/16 are masked).
     const float *st_prev, *st_gate, *st_up;
     float rms_eps, ln_eps;
+    // RES_LN_RMS, BIAS kernels: bias [K] of the projection that produced u_prev (o_proj with config.attention_bias,
+    // modeling_bitllama.py:454): r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120 then :912)
+    const _Float16 *bias_prev;
     // WGP kernels (one projection per workgroup): workgroups [wg_end[p-1], wg_end[p]) own the tiles of projection p
     int wg_end[3];
     // EMBED_RMS (first launch of a step), optional: workgroup 0 copies the rotary rows of the current position,
@@ -461,10 +464,11 @@ __device__ __forceinline__ void ob_st8(_Float16 *p, const ob_half8 v)
 // wave and step; at 128 B/clk the q|k|v launch spent ~1500 cycles per workgroup on those reads: the gap between
 // "digits in LDS" and "first MFMA" in tools/phase_probe.py).  With one projection per workgroup the prologue quantises
 // once and each B operand feeds MS MFMAs.
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
     static_assert(!WGP || NPROJ == 1, "WGP kernels are instantiated with NPROJ = 1");
+    static_assert(!BIAS || PRO == OB_P_RES_LN_RMS, "only the residual prologue adds the producer's bias");
     constexpr int MT = MS * NPROJ;
     // digit sums from the matrix pipe where several projections share the launch (gate|up, q|k|v: measured 7.16 -> 6.66 us
     // and 6.57 -> 6.6 us per launch); a single-projection launch with KV = 3 chunks per wave (down) would double its MFMA
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     // every prologue argument is requested in the first scalar-load clause (hipcc fetches kernel arguments where they are
     // first used: a second s_load / s_waitcnt round trip stood in front of the vector requests)
     if (PRO == OB_P_RES_LN_RMS) asm volatile("" :: "s"(A.hres_in), "s"(A.u_prev), "s"(A.hres_out), "s"(A.rms_w), "s"(A.st_prev), "s"(A.K));
+    if (BIAS) asm volatile("" :: "s"(A.bias_prev));
     if (PRO == OB_P_EMBED_RMS) asm volatile("" :: "s"(A.embed), "s"(A.token), "s"(A.hres_out), "s"(A.rms_w), "s"(A.K));
     if (PRO == OB_P_SWIGLU) asm volatile("" :: "s"(A.u_gate), "s"(A.u_up), "s"(A.st_gate), "s"(A.st_up), "s"(A.K));
     if (PRO == OB_P_PLAIN) asm volatile("" :: "s"(A.xin), "s"(A.K));
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     // 1a. prologue vectors (raw halves; indices clamped, masked later)
     bool valid[KV];
     int vbase[KV];
-    ob_half8 v0[KV], v1[KV], v2[KV], hp[NPROJ][KV];
+    ob_half8 v0[KV], v1[KV], v2[KV], hp[NPROJ][KV], vb[KV];
     _Float16 c0h = (_Float16)0, c1h = (_Float16)0;
     // the LayerNorm partials first (requests return in order and the statistics are what the prologue needs first), the
     // consumers' input_factor rows last (needed after the whole elementwise chain)
@@ -581,6 +586,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
             if (PRO == OB_P_RES_LN_RMS) {
                 v0[v] = ob_ld8<SD>(A.u_prev + vbase[v]);
                 v1[v] = ob_ld8<SD>(A.hres_in + vbase[v]);
+                if (BIAS) vb[v] = ob_ld8<SD>(A.bias_prev + vbase[v]);
             }
             v2[v] = ob_ld8<SD>(A.rms_w + vbase[v]);
         }
@@ -758,6 +764,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 ob_half8 ln;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ln[i] = ob_ln_apply_h(v0[v][i], rstd, nmr);
+                if (BIAS) ln = ln + vb[v];          // output += bias, bitnet.py:119-120 (one fp16 rounding)
                 hv[v] = v1[v] + ln;                 // residual + hidden_states, modeling_bitllama.py:912,918
             }
         } else {
@@ -1160,6 +1167,8 @@ struct ObAttnArgs {
     const _Float16 *rope_cur;            // optional [2 * D]: cos[pos] | sin[pos] copied by the step's first launch (no pos -> table chase here)
     const _Float16 *h_next;              // optional [H * D]: out <- fp16(out * h_next), o_proj's input scaling (bitnet.py:113)
                                          // for a consumer that takes pre-scaled rows (batched step, ob_skinny3.h)
+    const _Float16 *b_q, *b_k, *b_v;     // BIAS kernels (config.attention_bias, modeling_bitllama.py:451-453): q / k / v =
+                                         // fp16(LayerNorm(u) + b) (bitnet.py:118-120) before the rotary embedding
 };
 
 // Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and
@@ -1203,7 +1212,7 @@ __device__ __forceinline__ float ob_rows_max(float v)
 // PF (single sequence only): the launch runs one workgroup per head on a 256-CU chip -- the grid carries one extra
 // workgroup per idle CU that does nothing but pull o_proj's packed rows (the next launch: 2 MB) into the L2 of the XCD
 // whose workgroups will read them (ob_common.h).
-template <bool PST, int NTH, bool BLIND = true>
+template <bool PST, int NTH, bool BLIND = true, bool BIAS = false>
 __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in, const ObPfPlan PF)
 {
     ObAttnArgs A = A_in;
@@ -1260,6 +1269,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
     const int d0 = min(lane, half - 1), d1 = d0 + half;
     ObTileStatsRt tr;
     _Float16 ur0 = (_Float16)0, ur1 = (_Float16)0, rc0 = (_Float16)0, rs0 = (_Float16)0, rc1 = (_Float16)0, rs1 = (_Float16)0;
+    _Float16 br0 = (_Float16)0, br1 = (_Float16)0;
     const float *st_r = role == 0 ? A.st_q : (role == 1 ? A.st_k : A.st_v);
     const int n_r = role == 0 ? NQ : NK;
     if (PST) {
@@ -1267,15 +1277,24 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         if (role < 3) {                                                           // (wave-uniform)
             ob_tiles_load_rt(tr, st_r, n_r, lane);
             ur0 = ub[d0]; ur1 = ub[d1];
+            if (BIAS) {
+                const _Float16 *bb = role == 0 ? A.b_q + head * D : (role == 1 ? A.b_k + kvh * D : A.b_v + kvh * D);
+                br0 = bb[d0]; br1 = bb[d1];
+            }
             if (A.rope_cur) { rc0 = A.rope_cur[d0]; rs0 = A.rope_cur[D + d0]; rc1 = A.rope_cur[d1]; rs1 = A.rope_cur[D + d1]; }
         }
     }
     const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
     const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
     _Float16 uqh = (_Float16)0, ukh = (_Float16)0, uvh = (_Float16)0, uqp = (_Float16)0, ukp = (_Float16)0;
+    _Float16 bqh = (_Float16)0, bkh = (_Float16)0, bvh = (_Float16)0, bqp = (_Float16)0, bkp = (_Float16)0;
     if (!PST) {
         uqh = A.u_q[head * D + dq]; ukh = A.u_k[kvh * D + dq]; uvh = A.u_v[kvh * D + dq];
         uqp = A.u_q[head * D + dp]; ukp = A.u_k[kvh * D + dp];
+        if (BIAS) {
+            bqh = A.b_q[head * D + dq]; bkh = A.b_k[kvh * D + dq]; bvh = A.b_v[kvh * D + dq];
+            bqp = A.b_q[head * D + dp]; bkp = A.b_k[kvh * D + dp];
+        }
     }
     const _Float16 hnx = A.h_next ? A.h_next[head * D + dq] : (_Float16)1;
     _Float16 cosh_ = (_Float16)0, sinh_ = (_Float16)0;
@@ -1321,7 +1340,8 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             float mr, rr;
             ob_tiles_combine_rt(tr, st_r, n_r, A.ln_eps, lane, mr, rr);
             // apply_rotary_pos_emb (:175-181): x*cos + rotate_half(x)*sin, each op rounded to fp16; v: LayerNorm only
-            const float y0 = ob_ln_apply((float)ur0, mr, rr), y1 = ob_ln_apply((float)ur1, mr, rr);
+            float y0 = ob_ln_apply((float)ur0, mr, rr), y1 = ob_ln_apply((float)ur1, mr, rr);
+            if (BIAS) { y0 = ob_round_h(y0 + (float)br0); y1 = ob_round_h(y1 + (float)br1); }     // output += bias (bitnet.py:119-120)
             float e0 = y0, e1 = y1;
             if (role < 2) {
                 e0 = ob_round_h(ob_round_h(y0 * (float)rc0) + ob_round_h(-y1 * (float)rs0));
@@ -1359,9 +1379,14 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         if (tid < D) {
             // apply_rotary_pos_emb (:175-181): q*cos + rotate_half(q)*sin, each op rounded to fp16
             const float c = (float)cosh_, sn = (float)sinh_;
-            const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
-            const float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
+            float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
+            float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
             ve = ob_ln_apply((float)uvh, mv, rv);
+            if (BIAS) {
+                q0 = ob_round_h(q0 + (float)bqh); q1 = ob_round_h(q1 + (float)bqp);
+                k0 = ob_round_h(k0 + (float)bkh); k1 = ob_round_h(k1 + (float)bkp);
+                ve = ob_round_h(ve + (float)bvh);
+            }
             const float qr = tid < half ? -q1 : q1, kr = tid < half ? -k1 : k1;
             qe = ob_round_h(ob_round_h(q0 * c) + ob_round_h(qr * sn));
             ke = ob_round_h(ob_round_h(k0 * c) + ob_round_h(kr * sn));
@@ -1553,6 +1578,10 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(con
     const _Float16 uqh = A.u_q[head * D + dq], ukh = A.u_k[kvh * D + dq], uvh = A.u_v[kvh * D + dq];
     const _Float16 uqp = A.u_q[head * D + dp], ukp = A.u_k[kvh * D + dp];
     const _Float16 cosh_ = A.cos[(int64_t)pos * D + dq], sinh_ = A.sin[(int64_t)pos * D + dq];
+    const bool has_b = A.b_q != nullptr;                     // config.attention_bias (uniform)
+    const _Float16 bqh = has_b ? A.b_q[head * D + dq] : (_Float16)0, bkh = has_b ? A.b_k[kvh * D + dq] : (_Float16)0,
+                   bvh = has_b ? A.b_v[kvh * D + dq] : (_Float16)0, bqp = has_b ? A.b_q[head * D + dp] : (_Float16)0,
+                   bkp = has_b ? A.b_k[kvh * D + dp] : (_Float16)0;
     float mq, rq, mk, rk, mv, rv;
     if (A.st_q) {                                            // producer's tile partials (uniform branch)
         ObTileStatsRt tq, tk, tv;
@@ -1581,9 +1610,14 @@ __global__ __launch_bounds__(OB_ATTN_THREADS) void ob_dec_attn_scores_kernel(con
         float qe = 0.f, ke = 0.f;
         if (tid < D) {
             const float c = (float)cosh_, sn = (float)sinh_;
-            const float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
-            const float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
-            const float ve = ob_ln_apply((float)uvh, mv, rv);
+            float q0 = ob_ln_apply((float)uqh, mq, rq), q1 = ob_ln_apply((float)uqp, mq, rq);
+            float k0 = ob_ln_apply((float)ukh, mk, rk), k1 = ob_ln_apply((float)ukp, mk, rk);
+            float ve = ob_ln_apply((float)uvh, mv, rv);
+            if (has_b) {                                     // output += bias (bitnet.py:119-120), one fp16 rounding each
+                q0 = ob_round_h(q0 + (float)bqh); q1 = ob_round_h(q1 + (float)bqp);
+                k0 = ob_round_h(k0 + (float)bkh); k1 = ob_round_h(k1 + (float)bkp);
+                ve = ob_round_h(ve + (float)bvh);
+            }
             const float qr = tid < half ? -q1 : q1, kr = tid < half ? -k1 : k1;
             qe = ob_round_h(ob_round_h(q0 * c) + ob_round_h(qr * sn));
             ke = ob_round_h(ob_round_h(k0 * c) + ob_round_h(kr * sn));

@@ -3,6 +3,7 @@
 // the caller's stream.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -605,12 +606,12 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false>
 static void ob_launch_dec_gemv_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
     static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP>, attr_set, 160 * 1024);
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS>, attr_set, 160 * 1024);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
 }
 
 // PST (statistics from the producers' tile partials) exists for the prologues that normalise an
@@ -736,7 +737,9 @@ static bool ob_dec_wgp_geometry(const ObGemvArgs &a, int &MS, int (&wg_end)[3])
 template <int KV, int MS>
 static bool ob_launch_dec_gemv_wgp(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
-    if (a.prologue == OB_P_RES_LN_RMS && a.st_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true>(a, G, lds, s);
+    if (a.prologue == OB_P_RES_LN_RMS && a.st_prev && a.bias_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true, true>(a, G, lds, s);
+    else if (a.bias_prev) return false;
+    else if (a.prologue == OB_P_RES_LN_RMS && a.st_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true>(a, G, lds, s);
     else if (a.prologue == OB_P_RES_LN_RMS) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, false, true>(a, G, lds, s);
     else if (a.prologue == OB_P_EMBED_RMS) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_EMBED_RMS, 1, 1, false, true>(a, G, lds, s);
     else return false;
@@ -770,6 +773,12 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
             if (hit && ok) return ob_launch_status("decode gemv");
         }
     }
+    // the producer's bias (o_proj with config.attention_bias) exists in the one-projection-per-workgroup kernels fed with tile
+    // partials -- what onebit_decode_step launches for every LLaMA shape; no other instance carries it
+    if (a.bias_prev)
+        return ob_fail(ONEBIT_E_SHAPE, "decode gemv: o_proj bias needs the WGP kernels (>= 2 projections, K %% 128 == 0, K <= 8192, 16-byte "
+                                       "aligned rows) and the producer's tile partials (state->tile_stats, N %% 16 == 0); decode this "
+                                       "checkpoint through the module path");
     if (!aligned && KV != 1)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
     const int MT = MS * a.nproj;
@@ -1241,7 +1250,17 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         //  0.5 us off the o_proj launch; nor do the 64 CUs the q|k|v launch leaves idle: the attention launch's K / V
         //  stream runs through the same L2 in between, 2.18 vs 2.19 ms)
         if (sk3) at.h_next = (const _Float16 *)L.o.input_factor;
-        if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
+        at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
+        const bool qkv_bias = L.q_bias || L.k_bias || L.v_bias;
+        if (qkv_bias && !(L.q_bias && L.k_bias && L.v_bias))
+            return ob_fail(ONEBIT_E_ARG, "decode_step_batched: layer %d has some but not all of q_bias / k_bias / v_bias", l);
+        if (qkv_bias) {             // config.attention_bias: the BIAS instances
+            if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false, true>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
+            else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false, true>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
+            else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false, true>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
+            else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false, true>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
+        }
+        else if (attn_pst && battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
         else if (attn_pst) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
         else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
@@ -1256,6 +1275,7 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         nb.hres_in = hB; nb.u_prev = (const _Float16 *)st->u_o;
         if ((splitk_o && !sk3) || o_split) { nb.u_prev = nullptr; nb.z0 = zs0; nb.z1 = zs1; nb.g_prev = (const _Float16 *)L.o.weight_scale; }
         nb.rms_w = (const _Float16 *)L.post_attention_layernorm_w; nb.hres_out = hA;
+        nb.bias_prev = (const _Float16 *)L.o_bias;            // o_proj's bias joins LayerNorm(u_o) here (bitnet.py:119-120)
         if (sk3) {
             nb.x = nullptr; nb.n_scaled = 2; nb.h_next[2] = nullptr; nb.x_scaled[2] = nullptr;
             nb.h_next[0] = (const _Float16 *)L.gate.input_factor; nb.h_next[1] = (const _Float16 *)L.up.input_factor;
@@ -1295,6 +1315,10 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
 // side streams / events for the chain split of the batched step (per device; created on the first call, which must
 // not be inside a stream capture -- callers warm up once before capturing, as every graph user of this library does)
 struct ObChainCtx { hipStream_t side[3]; hipEvent_t fork, join[3]; bool ok; };
+// One set of side streams / events per device, shared by every caller: creation AND use are serialised by g_chain_mu (two host
+// threads, or two engines on different user streams of one device, would otherwise interleave record / wait on the same
+// events).  The split is an A/B switch that measured slower than one chain; it is kept correct, not concurrent.
+static std::mutex g_chain_mu;
 static ObChainCtx *ob_chain_ctx()
 {
     static ObChainCtx ctx[OB_MAX_DEVICES] = {};
@@ -1313,6 +1337,9 @@ static ObChainCtx *ob_chain_ctx()
 extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_batch_state_t *st, void *stream)
 {
     if (!m || !st) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null model/state");
+    if (st->struct_size != sizeof(onebit_batch_state_t))
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: state struct_size %llu != %zu (caller built against another ABI: this library is ABI %d)",
+                       (unsigned long long)st->struct_size, sizeof(onebit_batch_state_t), ONEBIT_ABI_VERSION);
     if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
         m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
         m->intermediate % 8 != 0 || m->max_len <= 0)
@@ -1340,11 +1367,19 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     if (chains <= 1) {
         if ((rc = ob_batched_layers(m, st, 0, s))) return rc;
     } else {
+        std::lock_guard<std::mutex> chain_lock(g_chain_mu);
         ObChainCtx *cx = ob_chain_ctx();
         if (!cx) return ob_fail(ONEBIT_E_ARG, "decode_step_batched: cannot create the side streams of the chain split");
         const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
         if (hipEventRecord(cx->fork, s) != hipSuccess) return ob_launch_status("decode_step_batched(fork)");
         const int per = B / chains;
+        int forked = 0;                 // side streams that wait on the fork: every one of them is joined, also on an error return
+        auto join_all = [&]() -> bool { // (an unjoined side stream would invalidate an active stream capture)
+            bool ok = true;
+            for (int c = 1; c <= forked; ++c)
+                ok = hipEventRecord(cx->join[c - 1], cx->side[c - 1]) == hipSuccess && hipStreamWaitEvent(s, cx->join[c - 1], 0) == hipSuccess && ok;
+            return ok;
+        };
         for (int c = 0; c < chains; ++c) {
             const int r0 = c * per, nb = c == chains - 1 ? B - r0 : per;
             onebit_batch_state_t v = *st;
@@ -1357,13 +1392,13 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
             v.qkv_stats = st->qkv_stats ? st->qkv_stats + (size_t)r0 * (fq + 2 * fk) : nullptr;     // a group's [3][nb] blocks
             v.x_scaled = st->x_scaled ? (void *)((_Float16 *)st->x_scaled + (size_t)r0 * 3 * H) : nullptr;   // a group's [3][nb][H]
             hipStream_t cs = c == 0 ? s : cx->side[c - 1];
-            if (c > 0 && hipStreamWaitEvent(cs, cx->fork, 0) != hipSuccess) return ob_launch_status("decode_step_batched(fork wait)");
-            if ((rc = ob_batched_layers(m, &v, r0, cs))) return rc;
             if (c > 0) {
-                if (hipEventRecord(cx->join[c - 1], cs) != hipSuccess || hipStreamWaitEvent(s, cx->join[c - 1], 0) != hipSuccess)
-                    return ob_launch_status("decode_step_batched(join)");
+                if (hipStreamWaitEvent(cs, cx->fork, 0) != hipSuccess) { (void)join_all(); return ob_launch_status("decode_step_batched(fork wait)"); }
+                forked = c;
             }
+            if ((rc = ob_batched_layers(m, &v, r0, cs))) { (void)join_all(); return rc; }
         }
+        if (!join_all()) return ob_launch_status("decode_step_batched(join)");
     }
     return ob_batched_head(m, st, s);
 }
@@ -1433,6 +1468,9 @@ extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, 
 extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_state_t *st, void *stream)
 {
     if (!m || !st || !m->layers) return ob_fail(ONEBIT_E_ARG, "decode_step: null model/state");
+    if (st->struct_size != sizeof(onebit_decode_state_t))
+        return ob_fail(ONEBIT_E_ARG, "decode_step: state struct_size %llu != %zu (caller built against another ABI: this library is ABI %d)",
+                       (unsigned long long)st->struct_size, sizeof(onebit_decode_state_t), ONEBIT_ABI_VERSION);
     if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
         m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 8 != 0 ||
         m->intermediate % 8 != 0 || m->max_len <= 0 || m->vocab <= 0)
@@ -1441,8 +1479,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         !st->u_o || !st->u_gate || !st->u_up || !st->u_down || !st->logits || !st->part_val || !st->part_idx ||
         !m->embed || !m->final_norm_w || !m->lm_head || !m->rope_cos || !m->rope_sin)
         return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer");
-    // tile_stats == NULL (a caller written against ABI <= 2 that zero-initialises the state): every consumer
-    // recomputes its LayerNorm statistics from the vectors -- the kernels' non-PST forms
+    // tile_stats == NULL: every consumer recomputes its LayerNorm statistics from the vectors -- the kernels' non-PST forms
     if (st->tile_stats && !ob_aligned(st->tile_stats, 16))
         return ob_fail(ONEBIT_E_ALIGN, "decode_step: tile_stats must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -1460,6 +1497,9 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         const onebit_layer_t &L = m->layers[l];
         if (!L.k_cache || !L.v_cache || !L.input_layernorm_w || !L.post_attention_layernorm_w)
             return ob_fail(ONEBIT_E_ARG, "decode_step: null buffer in layer %d", l);
+        const bool qkv_bias = L.q_bias || L.k_bias || L.v_bias;
+        if (qkv_bias && !(L.q_bias && L.k_bias && L.v_bias))
+            return ob_fail(ONEBIT_E_ARG, "decode_step: layer %d has some but not all of q_bias / k_bias / v_bias", l);
         // K1: residual (+LN of previous down) -> RMSNorm -> q, k, v
         ObGemvArgs a = {};
         a.nproj = 3; a.K = H;
@@ -1497,6 +1537,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.ln_eps = m->ln_eps;
         at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
         if (rope_cur) at.rope_cur = (const _Float16 *)st->rope_cur;
+        at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
         if (st->attn_splits > 1 && st->attn_scratch) {
             const int S = st->attn_splits;
             if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);
@@ -1525,7 +1566,12 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
             ObPfPlan apf = {};
             if (attn_pf_env && m->n_heads < ob_cu_count()) apf = ob_dec_gemv_plan(o);
             const int agrid = apf.nseg ? ob_cu_count() : m->n_heads;
-            if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
+            if (qkv_bias) {         // config.attention_bias: the BIAS instances (q / k / v = fp16(LayerNorm(u) + b) before RoPE)
+                if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
+                else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, true, true>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
+                else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, true>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
+            }
+            else if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
             else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
             else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
             if ((rc = ob_launch_status("decode_step(attn)"))) return rc;
@@ -1539,6 +1585,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         if ((rc = ob_fill_proj(gu.p[1], L.up, st->u_up, "up_proj", ts_up))) return rc;
         gu.hres_in = hB; gu.u_prev = (const _Float16 *)st->u_o; gu.hres_out = hA;
         gu.st_prev = ts_o;
+        gu.bias_prev = (const _Float16 *)L.o_bias;          // o_proj's bias joins LayerNorm(u_o) in this launch's prologue
         gu.rms_w = (const _Float16 *)L.post_attention_layernorm_w;
         gu.rms_eps = m->rms_eps; gu.ln_eps = m->ln_eps;
         if ((rc = ob_launch_dec_gemv(gu, s))) return rc;

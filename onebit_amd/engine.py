@@ -33,7 +33,8 @@ class _Proj(ctypes.Structure):
 class _Layer(ctypes.Structure):
     _fields_ = [("q", _Proj), ("k", _Proj), ("v", _Proj), ("o", _Proj), ("gate", _Proj), ("up", _Proj),
                 ("down", _Proj), ("input_layernorm_w", _vp), ("post_attention_layernorm_w", _vp),
-                ("k_cache", _vp), ("v_cache", _vp)]
+                ("k_cache", _vp), ("v_cache", _vp),
+                ("q_bias", _vp), ("k_bias", _vp), ("v_bias", _vp), ("o_bias", _vp)]          # ABI 8: config.attention_bias
 
 
 class _Model(ctypes.Structure):
@@ -44,7 +45,8 @@ class _Model(ctypes.Structure):
 
 
 class _State(ctypes.Structure):
-    _fields_ = [("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
+    _fields_ = [("struct_size", ctypes.c_uint64),      # ABI 8: checked by the library (a state of another ABI is refused, not misread)
+                ("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp),
@@ -52,7 +54,7 @@ class _State(ctypes.Structure):
 
 
 class _BatchState(ctypes.Structure):
-    _fields_ = [("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
+    _fields_ = [("struct_size", ctypes.c_uint64), ("batch", _i32), ("tokens", _vp), ("pos", _vp), ("hres0", _vp), ("hres1", _vp), ("x", _vp),
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp),
@@ -110,12 +112,14 @@ def fp16_view(model: OneBitLlamaForCausalLM) -> OneBitLlamaForCausalLM:
     return copy.deepcopy(model, memo).half()
 
 
-def _proj(m: BitLinearInf) -> _Proj:
-    if m.bias is not None:
+def _proj(m: BitLinearInf, allow_bias: bool = False) -> _Proj:
+    if m.bias is not None and not allow_bias:
         raise ValueError(
-            "the fused decode engines cover projections without bias (config.attention_bias=False, the default of "
-            "configuration_bitllama.py and of every released OneBit checkpoint); for a checkpoint with attention_bias=True "
-            "decode through the module path instead: model.generate(...) or ContinuousBatcher(..., native=False)")
+            "the fused decode engines take a projection bias on q / k / v / o_proj only (config.attention_bias, "
+            "modeling_bitllama.py:451-454: the reference's MLP projections have none); decode this checkpoint through the module "
+            "path instead: model.generate(...) or ContinuousBatcher(..., native=False)")
+    if m.bias is not None and (m.bias.dtype != torch.float16 or not m.bias.is_contiguous()):
+        raise ValueError("the fused decode engines run fp16 parameters: pass the model through engine.fp16_view()")
     if m.weight_scale.dtype != torch.float16 or m.input_factor.dtype != torch.float16:
         raise ValueError("the fused decode engines run fp16 parameters: pass the model through engine.fp16_view()")
     if m.in_features % 32 != 0:
@@ -141,10 +145,15 @@ def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int):
         for w in (layer.input_layernorm.weight, layer.post_attention_layernorm.weight):
             if w.dtype != f16:
                 raise ValueError("the decode steps need fp16 RMSNorm weights")
-        layers[i] = _Layer(_proj(a.q_proj), _proj(a.k_proj), _proj(a.v_proj), _proj(a.o_proj),
+        qkv_b = [p_.bias is not None for p_ in (a.q_proj, a.k_proj, a.v_proj)]
+        if any(qkv_b) and not all(qkv_b):
+            raise ValueError("the fused decode engines need a bias on all of q / k / v_proj or on none (config.attention_bias)")
+        bptr = lambda p_: None if p_.bias is None else p_.bias.data_ptr()
+        layers[i] = _Layer(_proj(a.q_proj, True), _proj(a.k_proj, True), _proj(a.v_proj, True), _proj(a.o_proj, True),
                            _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
                            layer.input_layernorm.weight.data_ptr(),
-                           layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr())
+                           layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                           bptr(a.q_proj), bptr(a.k_proj), bptr(a.v_proj), bptr(a.o_proj))
     m = _Model(cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads,
                cfg.num_key_value_heads, cfg.head_dim, cfg.vocab_size, max_len, cfg.rms_norm_eps, 1e-5, layers,
                model.model.embed_tokens.weight.data_ptr(), model.model.norm.weight.data_ptr(),
@@ -182,7 +191,7 @@ class DecodeEngine:
                         u_gate=z(I), u_up=z(I), u_down=z(H), logits=z(cfg.vocab_size),
                         part_val=z(1024, torch.float32), part_idx=z(1024, torch.int32))
         b = self.buf
-        self._state = _State(self.token.data_ptr(), self.pos.data_ptr(), self.out_tokens.data_ptr(), self.max_len,
+        self._state = _State(ctypes.sizeof(_State), self.token.data_ptr(), self.pos.data_ptr(), self.out_tokens.data_ptr(), self.max_len,
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
@@ -368,7 +377,7 @@ class BatchedDecodeStep:
             if keep_logits:
                 self.logits = torch.zeros(batch, cfg.vocab_size, dtype=f16, device=dev)
                 lg = self.logits.data_ptr()
-        self._state = _BatchState(batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
+        self._state = _BatchState(ctypes.sizeof(_BatchState), batch, self.tokens.data_ptr(), self.pos.data_ptr(), b["hres0"].data_ptr(),
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
                                   b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None, None,

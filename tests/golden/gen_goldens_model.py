@@ -42,6 +42,10 @@ CONFIGS = {
     # b: every projection on the MFMA path; head_dim 64
     "b": dict(vocab_size=96, hidden_size=128, intermediate_size=352, num_hidden_layers=2,
               num_attention_heads=2, max_position_embeddings=64),
+    # bias: config.attention_bias = True -- q / k / v / o_proj carry a bias added after their LayerNorm
+    # (modeling_bitllama.py:451-454, bitnet.py:119-120); shapes of "b", 3 layers
+    "bias": dict(vocab_size=96, hidden_size=128, intermediate_size=352, num_hidden_layers=3,
+                 num_attention_heads=2, max_position_embeddings=64, attention_bias=True),
 }
 
 
@@ -91,5 +95,7 @@ def run(name, kw):
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    only = sys.argv[1:]                       # e.g. `gen_goldens_model.py bias`: regenerate one fixture
     for n, kw in CONFIGS.items():
-        run(n, kw)
+        if not only or n in only:
+            run(n, kw)

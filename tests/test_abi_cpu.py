@@ -63,10 +63,19 @@ def test_argument_errors_without_gpu():
     from onebit_amd.engine import _BatchState, _Layer, _Model
     layers = (_Layer * 1)()
     m = _Model(1, 64, 128, 2, 2, 32, 16, 8, 1e-6, 1e-5, layers, a, a, a, a, a)
-    st = _BatchState(1, a, a, a, a, a, a, a, a, a, a, a, a, a, a)
+    st = _BatchState(ctypes.sizeof(_BatchState), 1, a, a, a, a, a, a, a, a, a, a, a, a, a, a)
     lib.onebit_decode_step_batched.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_BatchState), ctypes.c_void_p]
     assert lib.onebit_decode_step_batched(ctypes.byref(m), ctypes.byref(st), None) == E_SHAPE      # batch 1
     assert b"batch" in lib.onebit_last_error()
+    # ABI 8: a state built against another header (another size) is refused before any field is read
+    st.struct_size = ctypes.sizeof(_BatchState) - 8
+    assert lib.onebit_decode_step_batched(ctypes.byref(m), ctypes.byref(st), None) == E_ARG
+    assert b"struct_size" in lib.onebit_last_error()
+    from onebit_amd.engine import _State
+    ds = _State()
+    lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), ctypes.c_void_p]
+    assert lib.onebit_decode_step(ctypes.byref(m), ctypes.byref(ds), None) == E_ARG                # struct_size 0
+    assert b"struct_size" in lib.onebit_last_error()
     with pytest.raises(ValueError):
         _lib.check(E_SHAPE, "x")
     with pytest.raises(RuntimeError):

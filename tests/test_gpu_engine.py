@@ -312,18 +312,68 @@ def test_engine_accepts_fp32_checkpoint(golden_dir):
         BatchedDecodeStep(m32, m32.new_cache(2, 16).layers, 2, 16)
 
 
-def test_engine_bias_checkpoint_names_the_remedy(golden_dir):
-    from onebit_amd.engine import DecodeEngine
-    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+@pytest.mark.parametrize("route", ["module", "engine", "engine graph", "engine split-kv", "batched", "batched no-stats", "batched unscaled"])
+def test_attention_bias_checkpoint_vs_reference(golden_dir, route):
+    """config.attention_bias = True (modeling_bitllama.py:451-454: q / k / v / o_proj are built with a bias, added after the
+    projection's LayerNorm, bitnet.py:119-120).  Round 4 refused such checkpoints in the fused engines; now the attention
+    kernels add b_q / b_k / b_v before the rotary embedding and the gate|up prologue (batched: the post-attention row kernel)
+    adds b_o to LayerNorm(u_o).  Logits of every route against tests/golden/model_tiny_bias.npz, recorded from the
+    reference's BitLlamaForCausalLMInf with attention_bias=True (gen_goldens_model.py bias; 3 layers)."""
+    from onebit_amd.engine import BatchedDecodeStep, DecodeEngine
     dev = torch.device("cuda:0")
-    cfg = OneBitLlamaConfig(vocab_size=96, hidden_size=128, intermediate_size=352, num_hidden_layers=1, num_attention_heads=2,
-                            max_position_embeddings=64, attention_bias=True)
-    model = build_synthetic_model(cfg, seed=1, device=dev)
-    assert model.model.layers[0].self_attn.q_proj.bias is not None
-    with pytest.raises(ValueError, match="module path"):
-        DecodeEngine(model, max_len=32)
-    out = model.generate(torch.tensor([[1, 2, 3]], device=dev), max_new_tokens=2)      # the named remedy works
-    assert out.shape == (1, 5)
+    z, model = _golden_model(golden_dir, "bias", dev)
+    assert model.model.layers[0].self_attn.q_proj.bias is not None and model.model.layers[0].self_attn.o_proj.bias is not None
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    S = ids.shape[1]
+    ref16, ref32 = z["decode_logits_f16"][0], z["decode_logits_f32"][0]
+    tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
+    toks = z["greedy_f16"][0]
+    # the bias is not a no-op in this fixture: the same weights without it miss the reference by far more than the bar
+    if route == "module":
+        cache = model.new_cache(1, 32)
+        lg = model(ids, cache).cpu().numpy()
+        assert np.abs(lg - z["prefill_logits_f16"]).max() <= tol
+        tk = torch.from_numpy(z["greedy_f16"]).to(dev)
+        dec = np.concatenate([model(tk[:, i:i + 1], cache).cpu().numpy() for i in range(4)], axis=1)
+        assert np.abs(dec[0] - ref16).max() <= tol
+        for layer in model.model.layers:
+            for p_ in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj):
+                p_.bias = None
+        cache0 = model.new_cache(1, 32)
+        model(ids, cache0)
+        dec0 = model(tk[:, 0:1], cache0).cpu().numpy()
+        assert np.abs(dec0[0, 0] - ref16[0]).max() > 4 * tol
+        return
+    if route.startswith("engine"):
+        kw = dict(use_graph=route == "engine graph")
+        if route == "engine split-kv":
+            kw.update(long_context_from=4, attn_splits=2)        # every step on the two split-KV launches
+        eng = DecodeEngine(model, max_len=64, **kw)
+        eng.prefill(ids)
+        assert eng.first_token == int(toks[0])
+        for i in range(4):
+            eng.set_state(int(toks[i]), S + i)                   # teacher-forced with the reference's tokens
+            eng.step()
+            lg = eng.logits().cpu().numpy()
+            assert np.abs(lg - ref16[i]).max() <= tol, (route, i, float(np.abs(lg - ref16[i]).max()), tol)
+            assert np.abs(lg - ref32[i]).max() <= tol
+        return
+    # batched step: three slots decode the same sequence (every slot against the reference), one idle slot in between
+    B, max_len = 4, 32
+    cache = model.new_cache(B, max_len)
+    model(ids.repeat(B, 1), cache)
+    step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True,
+                             producer_stats=route != "batched no-stats", prescaled_rows=route != "batched unscaled")
+    for i in range(4):
+        step.tokens.fill_(int(toks[i]))
+        step.pos.fill_(S + i)
+        step.pos[2] = -1                                          # idle slot: computed, never appended
+        step.launch()
+        torch.cuda.synchronize()
+        got = step.logits.float().cpu().numpy()
+        for b_ in (0, 1, 3):
+            assert np.abs(got[b_] - ref16[i]).max() <= tol, (route, i, b_, float(np.abs(got[b_] - ref16[i]).max()), tol)
+        assert (step.next_tokens.cpu().numpy()[[0, 1, 3]] == got[[0, 1, 3]].argmax(-1)).all()
 
 
 @pytest.mark.parametrize("K,Ns", [
