@@ -346,7 +346,7 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
             dt = float(tmax.item())
         return dt
 
-    out = {"k_shards": world, "exchange": "all_reduce(fp32 [1,N]) per BitLinearInf call", "steps": steps,
+    out = {"k_shards": world, "exchange": "fused: all_reduce(fp32) of z_qkv / z_o / z_gu / z_down per layer (4); module paths: one per BitLinearInf call (7)", "steps": steps,
            "collectives_per_token": 7 * cfg.num_hidden_layers if world > 1 else 0}
     try:                                                               # the fused engine on the unsharded checkpoint
         from onebit_amd.engine import DecodeEngine
@@ -359,6 +359,22 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
         del eng
     except Exception as e:
         out["single_gpu_engine"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:    # round 5: native segments (onebit_decode_step_ksharded), q|k|v and gate|up one exchange each, ONE HIP graph
+        from onebit_amd.sharded import FusedKShardedDecoder
+        fdec = FusedKShardedDecoder(model, rank, world, max_len=max_len, use_graph=True)
+        fdec.prime(prompt)
+        dt = timed(fdec.step, 3)
+        L = cfg.num_hidden_layers
+        out["fused"] = {"ms_per_token": round(dt / steps * 1e3, 4), "tokens_per_s": round(steps / dt, 1),
+                        "path": "FusedKShardedDecoder: onebit_decode_step_ksharded segments (decode GEMV in fp32-partial form on the rank's "
+                                "K slice, row kernels, decode attention) + all_reduce(fp32) replayed as one HIP graph",
+                        "collectives_per_token": fdec.collectives_per_token, "launches_per_token": 10 * L + 3,
+                        "reduced_fp32_bytes_per_token": 4 * L * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim
+                                                                 + 2 * cfg.hidden_size + 2 * cfg.intermediate_size) if world > 1 else 0}
+        del fdec
+    except Exception as e:
+        out["fused"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
     shard_model_k(model, rank, world, mode="allreduce")
     torch.cuda.empty_cache()
     try:                                                               # sharded step as one HIP graph, collectives captured
@@ -379,8 +395,9 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
     dt = timed(eager_step, 2)
     out["eager"] = {"ms_per_token": round(dt / steps * 1e3, 3), "tokens_per_s": round(steps / dt, 2),
                     "path": "module path driven from Python (host-bound exchange test-bed, not a baseline)"}
-    # headline fields of this object: the graph figure when it exists
-    best = out["graph"] if "error" not in out["graph"] else out["eager"]
+    # headline fields of this object: the fused figure when it exists, else the module graph, else eager
+    best = out["fused"] if "error" not in out["fused"] else (out["graph"] if "error" not in out["graph"] else out["eager"])
+    out["collectives_per_token"] = best.get("collectives_per_token", out["collectives_per_token"])
     out["ms_per_token"], out["tokens_per_s"], out["path"] = best["ms_per_token"], best["tokens_per_s"], best["path"]
     return out
 

@@ -323,6 +323,49 @@ typedef struct onebit_batch_state {
 size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);
 int onebit_decode_step_batched(const onebit_model_t *model, const onebit_batch_state_t *state, void *stream);
 
+/* ---- K-sharded decode step (BASELINE config 4: LLaMA-13B decode, hidden dim sharded over 2 / 4 / 8 GPUs) -------------
+ * z = W+- . (h * x) is linear in K, so rank p keeps the byte-column slice W[:, K_p] of every packed
+ * matrix and h[K_p], multiplies its slice and the fp32 partial sums of the ranks are added BEFORE the rounding points of
+ * bitnet.py:115-118.  The exchange is the CALLER's (torch.distributed all_reduce over RCCL: this library has no
+ * communicator), so the step comes in SEGMENTS; between two segments the caller all-reduces the named fp32 buffer in place:
+ *
+ *   for every layer l:   segment ONEBIT_KSEG_QKV      -> all_reduce(z_qkv  [n_heads*D + 2*n_kv*D])      (q | k | v in ONE call)
+ *                        segment ONEBIT_KSEG_ATTN_O   -> all_reduce(z_o    [hidden])
+ *                        segment ONEBIT_KSEG_GATE_UP  -> all_reduce(z_gu   [2 * intermediate])           (gate | up in ONE call)
+ *                        segment ONEBIT_KSEG_DOWN     -> all_reduce(z_down [hidden])
+ *   then once:           segment ONEBIT_KSEG_HEAD     (final norm, fp16 lm_head, greedy token, position += 1)
+ *
+ * = 4 collectives per layer instead of one per BitLinearInf call (7), every launch a native kernel (the decode GEMV in its
+ * fp32-partial form on the rank's K slice, one-workgroup row kernels for the replicated glue, the decode attention kernel;
+ * 10 launches per layer), capturable with the collectives in ONE HIP graph.  Everything that is not a K-sliced product
+ * (LayerNorm / RMSNorm / RoPE / attention over the replicated KV cache / lm_head) is computed by every rank on identical
+ * inputs, hence identical results.  world = 1: no collective, the same arithmetic.
+ *
+ * The MODEL passed here describes the rank's slices: every onebit_proj_t has weight = first byte of the slice inside the
+ * full packed matrix (or a copy), K = slice width (a multiple of 128; weight and input_factor 16-byte aligned), ldw_bytes =
+ * the row pitch, input_factor = h[K_p], weight_scale (and the layer's biases) FULL; hidden / intermediate / heads are the
+ * full model's.  k0_* = first column of the slice inside the full input vector of the projections with that in_features.   */
+enum { ONEBIT_KSEG_QKV = 0, ONEBIT_KSEG_ATTN_O = 1, ONEBIT_KSEG_GATE_UP = 2, ONEBIT_KSEG_DOWN = 3, ONEBIT_KSEG_HEAD = 4 };
+typedef struct onebit_kshard_state {
+    uint64_t struct_size;       /* sizeof(onebit_kshard_state_t) as the caller compiled it (checked)                 */
+    int32_t *token, *pos, *out_tokens;      /* as onebit_decode_state_t                                             */
+    int32_t max_out;
+    void *hres0, *hres1;        /* fp16 [hidden] residual stream ping-pong                                           */
+    void *x;                    /* fp16 [hidden] normalised input of the next projections                            */
+    void *u_q, *u_k, *u_v;      /* fp16 [n_heads*D], [n_kv*D] x 2: fp16(fp16(z) * g) of the reduced sums              */
+    void *attn_out;             /* fp16 [n_heads*D]                                                                   */
+    void *u_gate, *u_up, *act;  /* fp16 [intermediate] x 3                                                           */
+    void *u_down;               /* fp16 [hidden]                                                                      */
+    float *z_qkv, *z_o, *z_gu, *z_down;     /* fp32 partial sums OUT of a segment, complete sums INTO the next one    */
+    void *logits;               /* fp16 [vocab]                                                                       */
+    float *part_val;            /* fp32 [1024] argmax partials                                                        */
+    int32_t *part_idx;          /* int32 [1024]                                                                       */
+    float *tile_stats;          /* fp32 [onebit_decode_stats_floats(model)]                                           */
+    int32_t k0_hidden, k0_attn, k0_inter;   /* slice origin for in_features = hidden / n_heads*D / intermediate       */
+} onebit_kshard_state_t;
+int onebit_decode_step_ksharded(const onebit_model_t *model, const onebit_kshard_state_t *state, int32_t layer,
+                                int32_t segment, void *stream);
+
 /* One fused decode GEMV launch (the building block of onebit_decode_step, exposed so that a
  * single kernel can be measured and tested in isolation): up to 3 projections sharing the input
  * vector x, each writing its pre-LayerNorm u = fp16(fp16(W.(h*x)) * g) to outs[i] (fp16 [N_i]).

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z0 + row + b0 + 4 * q);
-                    const ob_float4 b = *reinterpret_cast<const ob_float4 *>(A.z1 + row + b0 + 4 * q);
+                    // (z1 == NULL: one complete sum, the all-reduced partials of a K-sharded projection -- uniform test)
+                    const ob_float4 b = A.z1 ? *reinterpret_cast<const ob_float4 *>(A.z1 + row + b0 + 4 * q) : (ob_float4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         uv[v][4 * q + i] = (_Float16)(ob_round_h(a[i] + b[i]) * (float)gv[4 * q + i]);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     if (!EMBED) {
         // pivot of the shifted sums = element 0 of the row, the same value in every thread
         const float c0 = A.u_prev ? (float)A.u_prev[row]
-                                  : (float)(_Float16)(ob_round_h(A.z0[row] + A.z1[row]) * (float)A.g_prev[0]);
+                                  : (float)(_Float16)(ob_round_h(A.z0[row] + (A.z1 ? A.z1[row] : 0.f)) * (float)A.g_prev[0]);
         ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < NV; ++v)
@@ -123,6 +124,42 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
                 if (j < A.n_scaled) *reinterpret_cast<ob_half8 *>(A.x_scaled[j] + row + base) = xv * hn[j][v];
             *reinterpret_cast<ob_half8 *>(A.hres_out + row + base) = hv[v];
         }
+    }
+}
+
+// u = fp16(fp16(z) * g) (bitnet.py:115-116) for up to three vectors of COMPLETE fp32 sums z (the all-reduced partials of
+// K-sharded projections: onebit_decode_step_ksharded), optionally with the per-16-row-tile LayerNorm partials (sum, M2) the
+// decode kernels' PST forms combine.  Block b covers 4096 elements of its segment; a tile is a pair of adjacent lanes.
+struct ObBZgSeg { const float *z; const _Float16 *g; _Float16 *u; float *st; int n, blk_end; };
+struct ObBZgArgs { ObBZgSeg s[3]; };
+__global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_zg_kernel(const ObBZgArgs A)
+{
+    const int b = (int)blockIdx.x;
+    const int si = (b >= A.s[0].blk_end ? 1 : 0) + (b >= A.s[1].blk_end ? 1 : 0);
+    const ObBZgSeg S = si == 0 ? A.s[0] : (si == 1 ? A.s[1] : A.s[2]);
+    const int b0 = si == 0 ? 0 : (si == 1 ? A.s[0].blk_end : A.s[1].blk_end);
+    const int base = ((b - b0) * OB_DEC_THREADS + (int)threadIdx.x) * 8;
+    if (base >= S.n) return;                                 // n % 8 == 0 (n % 16 == 0 with st): lane pairs leave together
+    const ob_float4 z0 = *reinterpret_cast<const ob_float4 *>(S.z + base), z1 = *reinterpret_cast<const ob_float4 *>(S.z + base + 4);
+    const ob_half8 g = *reinterpret_cast<const ob_half8 *>(S.g + base);
+    ob_half8 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[i] = (_Float16)(ob_round_h(z0[i]) * (float)g[i]);
+        u[4 + i] = (_Float16)(ob_round_h(z1[i]) * (float)g[4 + i]);
+    }
+    *reinterpret_cast<ob_half8 *>(S.u + base) = u;
+    if (S.st) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm += (float)u[i];
+        sm += OB_DPP_F(sm, 0xB1, 0xF);                       // lane ^ 1: the other half of the 16-row tile
+        const float mean = sm * 0.0625f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = (float)u[i] - mean; m2 += d * d; }
+        m2 += OB_DPP_F(m2, 0xB1, 0xF);
+        if ((threadIdx.x & 1) == 0) *reinterpret_cast<ob_float2 *>(S.st + 2 * (base >> 4)) = (ob_float2){sm, m2};
     }
 }
 

@@ -74,6 +74,7 @@ struct ObGemvArgs {
     const _Float16 *rope_cos, *rope_sin;
     _Float16 *rope_out;
     int rope_D, rope_max;
+    int zout;                      // host-side selector of the ZOUT instances (fp32 partial sums of a K slice to ObProj.u); PLAIN only
     int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
     unsigned long long *dbg;       // profiling builds only: per-workgroup phase timestamps [grid][8]
 };
@@ -464,7 +465,11 @@ __device__ __forceinline__ void ob_st8(_Float16 *p, const ob_half8 v)
 // wave and step; at 128 B/clk the q|k|v launch spent ~1500 cycles per workgroup on those reads: the gap between
 // "digits in LDS" and "first MFMA" in tools/phase_probe.py).  With one projection per workgroup the prologue quantises
 // once and each B operand feeds MS MFMAs.
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false>
+// ZOUT (round 5, K-sharded decode: config 4): the launch multiplies a K SLICE of its projections (weight pointer, input_factor
+// and xin already offset to the slice, K = its width, ldw the full row pitch) and stores the fp32 partial sum z of every row to
+// ObProj.u (as float *) -- no rounding, no weight_scale, no LayerNorm partials: the caller all-reduces z across the K shards
+// and the consumer applies fp16(fp16(z) * g) (bitnet.py:115-116) to the complete sum.
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false, bool ZOUT = false>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGemvArgs A)
 {
     static_assert(!WGP || NPROJ == 1, "WGP kernels are instantiated with NPROJ = 1");
@@ -630,8 +635,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     const int n_raw = trow_o + (tid & 15);
     const bool fin = (tid < MT * 16) && tval_o && n_raw < N_o;
     const int n_out = min(n_raw, N_o - 1);
-    const _Float16 g_h = g_ptr[n_out];
-    float *st_out = tval_o ? st_sel : nullptr;
+    const _Float16 g_h = ZOUT ? (_Float16)1 : g_ptr[n_out];
+    float *st_out = (tval_o && !ZOUT) ? st_sel : nullptr;
     const int tile_out = trow_o >> 4;
     __builtin_amdgcn_sched_barrier(0);
     // 1d. packed weights: items (slot j, chunk wave + 8*ci); out-of-range items re-read a valid one.
@@ -855,12 +860,16 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
 #pragma unroll
             for (int w = 0; w < OB_DEC_WAVES; ++w) z += lds_red[((jo * OB_DEC_WAVES + w) << 4) + r];
             // z -> fp16 (bitnet.py:115), * g -> fp16 (:116)
-            const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);
-            u_out[n_out] = uh;
-            uval = (float)uh;
+            if (ZOUT) {
+                reinterpret_cast<float *>(u_out)[n_out] = z;
+            } else {
+                const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);
+                u_out[n_out] = uh;
+                uval = (float)uh;
+            }
         }
         // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
-        if (tid < MT * 16) {
+        if (!ZOUT && tid < MT * 16) {
             const float sm = ob_row16_sum(fin ? uval : 0.f);     // st_out is only given when N % 16 == 0: full tiles
             const float dv = fin ? uval - sm * 0.0625f : 0.f;
             const float m2 = ob_row16_sum(dv * dv);
@@ -1124,12 +1133,16 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
                 z2 += lo + hi;
             }
             const float z = z2[0] + z2[1];
-            const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);   // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
-            u_out[n_out] = uh;
-            uval = (float)uh;
+            if (ZOUT) {
+                reinterpret_cast<float *>(u_out)[n_out] = z;             // fp32 partial sum of this K slice (rounded by the consumer)
+            } else {
+                const _Float16 uh = (_Float16)(ob_round_h(z) * (float)g_h);   // fp16(z) (bitnet.py:115), * g -> fp16 (:116)
+                u_out[n_out] = uh;
+                uval = (float)uh;
+            }
         }
         // per-tile LayerNorm partials for the consumer kernels: the 16 rows of a tile are one DPP row
-        if (tid < MT * 16) {
+        if (!ZOUT && tid < MT * 16) {
             const float sm = ob_row16_sum(fin ? uval : 0.f);     // st_out is only given when N % 16 == 0: full tiles
             const float dv = fin ? uval - sm * 0.0625f : 0.f;
             const float m2 = ob_row16_sum(dv * dv);

@@ -606,12 +606,12 @@ static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *
     return 0;
 }
 
-template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false>
+template <int KV, int MS, bool ALIGNED, int PRO, int MATH, int NPROJ, bool PST, bool WGP = false, bool BIAS = false, bool ZOUT = false>
 static void ob_launch_dec_gemv_t2(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
     static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS>, attr_set, 160 * 1024);
-    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
+    ob_set_max_lds_once(ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS, ZOUT>, attr_set, 160 * 1024);
+    hipLaunchKernelGGL((ob_dec_gemv_kernel<KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS, ZOUT>), dim3(G), dim3(OB_DEC_THREADS), lds, s, a);
 }
 
 // PST (statistics from the producers' tile partials) exists for the prologues that normalise an
@@ -632,6 +632,12 @@ static void ob_launch_dec_gemv_t(const ObGemvArgs &a, int G, size_t lds, hipStre
 template <int KV, int MS, bool ALIGNED, int MATH>
 static bool ob_launch_dec_gemv_p(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
+    if (a.zout) {                        // fp32 partial sums of a K slice: integer-path PLAIN instances only
+        if constexpr (MATH == 1 && ALIGNED) {
+            if (a.prologue == OB_P_PLAIN && a.nproj == 1) { ob_launch_dec_gemv_t2<KV, MS, true, OB_P_PLAIN, 1, 1, false, false, false, true>(a, G, lds, s); return true; }
+        }
+        return false;
+    }
     if (a.prologue == OB_P_PLAIN && a.nproj == 1) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_PLAIN, MATH, 1>(a, G, lds, s);
     else if (a.prologue == OB_P_SWIGLU && a.nproj == 1) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_SWIGLU, MATH, 1>(a, G, lds, s);
     else if (a.prologue == OB_P_RES_LN_RMS && a.nproj == 2) ob_launch_dec_gemv_t<KV, MS, ALIGNED, OB_P_RES_LN_RMS, MATH, 2>(a, G, lds, s);
@@ -737,6 +743,11 @@ static bool ob_dec_wgp_geometry(const ObGemvArgs &a, int &MS, int (&wg_end)[3])
 template <int KV, int MS>
 static bool ob_launch_dec_gemv_wgp(const ObGemvArgs &a, int G, size_t lds, hipStream_t s)
 {
+    if (a.zout) {
+        if (a.prologue != OB_P_PLAIN) return false;
+        ob_launch_dec_gemv_t2<KV, MS, true, OB_P_PLAIN, 1, 1, false, true, false, true>(a, G, lds, s);
+        return true;
+    }
     if (a.prologue == OB_P_RES_LN_RMS && a.st_prev && a.bias_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true, true>(a, G, lds, s);
     else if (a.bias_prev) return false;
     else if (a.prologue == OB_P_RES_LN_RMS && a.st_prev) ob_launch_dec_gemv_t2<KV, MS, true, OB_P_RES_LN_RMS, 1, 1, true, true>(a, G, lds, s);
@@ -760,7 +771,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
     // launches of several projections: one projection per workgroup (OB_DEC_WGP=0: the per-slot form, A/B)
     static const int wgp_env = getenv("OB_DEC_WGP") ? atoi(getenv("OB_DEC_WGP")) : 1;
     if (wgp_env && a.nproj >= 2 && aligned && ob_decode_math() == 1 && KV <= 2 &&
-        (a.prologue == OB_P_RES_LN_RMS || a.prologue == OB_P_EMBED_RMS)) {
+        (a.prologue == OB_P_RES_LN_RMS || a.prologue == OB_P_EMBED_RMS || (a.prologue == OB_P_PLAIN && a.zout))) {
         int MSw;
         if (ob_dec_wgp_geometry(a, MSw, a.wg_end)) {
             const int Gw = a.wg_end[a.nproj - 1];
@@ -812,6 +823,10 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
 #undef OB_CASE
 #undef OB_CASE_U
     if (!hit) return ob_fail(ONEBIT_E_SHAPE, "decode gemv: no kernel instance for KV=%d MS=%d", KV, MS);
+    if (!ok && a.zout)
+        return ob_fail(ONEBIT_E_SHAPE, "decode gemv: the fp32-partial (K-sharded) form needs a K slice that is a multiple of 128 with 16-byte "
+                                       "aligned rows, the integer path, and 1 projection (or 2-3 with K <= 8192): prologue %d, %d projections, K = %d",
+                       a.prologue, a.nproj, a.K);
     if (!ok) return ob_fail(ONEBIT_E_FLAG, "decode gemv: prologue %d with %d projections is not instantiated "
                             "(PLAIN:1, SWIGLU:1, RES_LN_RMS:2|3, EMBED_RMS:3)", a.prologue, a.nproj);
     return ob_launch_status("decode gemv");
@@ -1613,6 +1628,173 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     hipLaunchKernelGGL(ob_dec_argmax_kernel, dim3(1), dim3(256), 0, s, (const float *)st->part_val,
                        (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out, m->vocab);
     return ob_launch_status("decode_step(argmax)");
+}
+
+// ------------------------------------------------------------ K-sharded decode step (config 4) --
+// SURVEY.md section 8(e); reference semantics bitnet.py:112-122 with the sum over K split across ranks before :115's rounding.
+static int ob_kshard_proj(ObProj &d, const onebit_proj_t &sp, float *z, int64_t n_expect, int64_t k_full, const char *name)
+{
+    if (!sp.weight || !sp.input_factor || !sp.weight_scale || !z)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null pointer in projection %s", name);
+    if (sp.N != n_expect || sp.K <= 0 || sp.K > k_full || sp.K % 128 != 0 || sp.ldw_bytes % 16 != 0 || sp.ldw_bytes < sp.K / 8 ||
+        !ob_aligned(sp.weight, 16) || !ob_aligned(sp.input_factor, 16))
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: projection %s: the K slice must be a multiple of 128 columns with 16-byte "
+                                       "aligned weight rows and input_factor (N = %lld, K = %lld of %lld, pitch %lld)", name,
+                       (long long)sp.N, (long long)sp.K, (long long)k_full, (long long)sp.ldw_bytes);
+    d.w = (const uint32_t *)sp.weight; d.h = (const _Float16 *)sp.input_factor; d.g = (const _Float16 *)sp.weight_scale;
+    d.u = (_Float16 *)z;                       // ZOUT instances: fp32 partial sums
+    d.st = nullptr;
+    d.N = (int)sp.N; d.K = (int)sp.K; d.ldw = (int)(sp.ldw_bytes / 4);
+    return 0;
+}
+
+extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit_kshard_state_t *st, int32_t l, int32_t segment, void *stream)
+{
+    if (!m || !st || !m->layers) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null model/state");
+    if (st->struct_size != sizeof(onebit_kshard_state_t))
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: state struct_size %llu != %zu (caller built against another ABI: this library is ABI %d)",
+                       (unsigned long long)st->struct_size, sizeof(onebit_kshard_state_t), ONEBIT_ABI_VERSION);
+    if (m->n_layers <= 0 || m->hidden <= 0 || m->n_heads <= 0 || m->n_kv_heads <= 0 || m->head_dim <= 0 ||
+        m->n_heads % m->n_kv_heads != 0 || m->head_dim % 8 != 0 || m->head_dim > 128 || m->hidden % 16 != 0 ||
+        m->intermediate % 16 != 0 || m->max_len <= 0 || m->vocab <= 0 || m->hidden > OB_DEC_MAXV * OB_DEC_THREADS * 8 ||
+        m->intermediate > OB_DEC_MAXV * OB_DEC_THREADS * 8 || (m->n_heads * m->head_dim) % 16 != 0 || (m->n_kv_heads * m->head_dim) % 16 != 0)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: unsupported model dimensions");
+    if (segment < ONEBIT_KSEG_QKV || segment > ONEBIT_KSEG_HEAD) return ob_fail(ONEBIT_E_FLAG, "decode_step_ksharded: unknown segment %d", segment);
+    if (segment != ONEBIT_KSEG_HEAD && (l < 0 || l >= m->n_layers)) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: layer %d", l);
+    if (!st->token || !st->pos || !st->hres0 || !st->hres1 || !st->x || !st->u_q || !st->u_k || !st->u_v || !st->attn_out || !st->u_gate ||
+        !st->u_up || !st->act || !st->u_down || !st->z_qkv || !st->z_o || !st->z_gu || !st->z_down || !st->logits || !st->part_val ||
+        !st->part_idx || !st->tile_stats || !m->embed || !m->final_norm_w || !m->lm_head || !m->rope_cos || !m->rope_sin)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null buffer");
+    if (!ob_aligned(st->tile_stats, 16) || !ob_aligned(st->z_qkv, 16) || !ob_aligned(st->z_o, 16) || !ob_aligned(st->z_gu, 16) ||
+        !ob_aligned(st->z_down, 16) || !ob_aligned(st->x, 16) || !ob_aligned(st->attn_out, 16) || !ob_aligned(st->act, 16))
+        return ob_fail(ONEBIT_E_ALIGN, "decode_step_ksharded: buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = m->hidden, I = m->intermediate, D = m->head_dim, NQ = m->n_heads * D, NK = m->n_kv_heads * D;
+    if (st->k0_hidden < 0 || st->k0_attn < 0 || st->k0_inter < 0 || st->k0_hidden % 128 || st->k0_attn % 128 || st->k0_inter % 128)
+        return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: slice origins must be multiples of 128");
+    _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
+    ObStatsLayout sl = ob_stats_layout(m);
+    float *ts = st->tile_stats;
+    float *ts_q = ts + sl.off[0], *ts_k = ts + sl.off[1], *ts_v = ts + sl.off[2], *ts_down = ts + sl.off[6];
+    int rc;
+    auto zg_blocks = [](int n) { return (n + OB_DEC_THREADS * 8 - 1) / (OB_DEC_THREADS * 8); };
+    auto launch_zg = [&](ObBZgArgs za, int nseg) -> int {
+        int tot = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (i < nseg) tot += zg_blocks(za.s[i].n);
+            else za.s[i] = za.s[nseg - 1];
+            za.s[i].blk_end = tot;
+        }
+        hipLaunchKernelGGL(ob_b_zg_kernel, dim3(tot), dim3(OB_DEC_THREADS), 0, s, za);
+        return ob_launch_status("decode_step_ksharded(scale)");
+    };
+    if (segment == ONEBIT_KSEG_HEAD) {
+        const onebit_layer_t &LL = m->layers[m->n_layers - 1];
+        ObBZgArgs za = {};
+        za.s[0] = {st->z_down, (const _Float16 *)LL.down.weight_scale, (_Float16 *)st->u_down, ts_down, H, 0};
+        if (!LL.down.weight_scale) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
+        if ((rc = launch_zg(za, 1))) return rc;
+        ObHeadArgs hd = {};
+        hd.hres_in = hA; hd.u_prev = (const _Float16 *)st->u_down; hd.rms_w = (const _Float16 *)m->final_norm_w;
+        hd.st_prev = ts_down;
+        hd.lm_w = (const _Float16 *)m->lm_head; hd.logits = (_Float16 *)st->logits;
+        hd.part_val = st->part_val; hd.part_idx = st->part_idx; hd.hres_out = hB;
+        hd.K = H; hd.V = m->vocab; hd.rms_eps = m->rms_eps; hd.ln_eps = m->ln_eps;
+        int G = ob_cu_count();
+        if (G > 1024) G = 1024;
+        const size_t head_lds = (size_t)H * 2 + 64 * 4 + 64 * 4;
+        hipLaunchKernelGGL(ob_dec_lmhead_kernel, dim3(G), dim3(OB_DEC_THREADS), head_lds, s, hd);
+        if ((rc = ob_launch_status("decode_step_ksharded(lm_head)"))) return rc;
+        hipLaunchKernelGGL(ob_dec_argmax_kernel, dim3(1), dim3(256), 0, s, (const float *)st->part_val,
+                           (const int *)st->part_idx, G, st->token, st->pos, st->out_tokens, st->max_out, m->vocab);
+        return ob_launch_status("decode_step_ksharded(argmax)");
+    }
+    const onebit_layer_t &L = m->layers[l];
+    if (!L.k_cache || !L.v_cache || !L.input_layernorm_w || !L.post_attention_layernorm_w)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null buffer in layer %d", l);
+    const bool qkv_bias = L.q_bias || L.k_bias || L.v_bias;
+    if (qkv_bias && !(L.q_bias && L.k_bias && L.v_bias))
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: layer %d has some but not all of q_bias / k_bias / v_bias", l);
+    ObGemvArgs a = {};
+    a.prologue = OB_P_PLAIN; a.zout = 1; a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
+    ObBNormArgs na = {};
+    na.H = H; na.rms_eps = m->rms_eps; na.ln_eps = m->ln_eps; na.x = (_Float16 *)st->x;
+    switch (segment) {
+    case ONEBIT_KSEG_QKV: {
+        // residual (+ LayerNorm of the previous layer's REDUCED down_proj sums) + input RMSNorm, once; then q | k | v on the slice
+        na.embed = (const _Float16 *)m->embed; na.tokens = st->token; na.hres_in = hA; na.hres_out = hB;
+        na.rms_w = (const _Float16 *)L.input_layernorm_w;
+        if (l > 0) { na.z0 = st->z_down; na.g_prev = (const _Float16 *)m->layers[l - 1].down.weight_scale;
+                     if (!na.g_prev) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale"); }
+        if (l == 0) OB_LAUNCH_NORM(true, H, dim3(1), s, na);
+        else OB_LAUNCH_NORM(false, H, dim3(1), s, na);
+        if ((rc = ob_launch_status("decode_step_ksharded(norm)"))) return rc;
+        a.nproj = 3; a.K = (int)L.q.K;
+        if (L.k.K != L.q.K || L.v.K != L.q.K || st->k0_hidden + L.q.K > H)
+            return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: q / k / v slices of layer %d differ or leave the input vector", l);
+        if ((rc = ob_kshard_proj(a.p[0], L.q, st->z_qkv, NQ, H, "q_proj"))) return rc;
+        if ((rc = ob_kshard_proj(a.p[1], L.k, st->z_qkv + NQ, NK, H, "k_proj"))) return rc;
+        if ((rc = ob_kshard_proj(a.p[2], L.v, st->z_qkv + NQ + NK, NK, H, "v_proj"))) return rc;
+        a.xin = (const _Float16 *)st->x + st->k0_hidden;
+        return ob_launch_dec_gemv(a, s);
+    }
+    case ONEBIT_KSEG_ATTN_O: {
+        ObBZgArgs za = {};
+        za.s[0] = {st->z_qkv, (const _Float16 *)L.q.weight_scale, (_Float16 *)st->u_q, ts_q, NQ, 0};
+        za.s[1] = {st->z_qkv + NQ, (const _Float16 *)L.k.weight_scale, (_Float16 *)st->u_k, ts_k, NK, 0};
+        za.s[2] = {st->z_qkv + NQ + NK, (const _Float16 *)L.v.weight_scale, (_Float16 *)st->u_v, ts_v, NK, 0};
+        if (!L.q.weight_scale || !L.k.weight_scale || !L.v.weight_scale) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
+        if ((rc = launch_zg(za, 3))) return rc;
+        ObAttnArgs at = {};
+        at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
+        at.cos = (const _Float16 *)m->rope_cos; at.sin = (const _Float16 *)m->rope_sin;
+        at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
+        at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
+        at.ln_eps = m->ln_eps;
+        at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
+        at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
+        const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
+        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: max_len %d too large for the attention kernel", m->max_len);
+        if (qkv_bias) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(m->n_heads), dim3(256), attn_lds, s, at, ObPfPlan{});
+        else hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(m->n_heads), dim3(256), attn_lds, s, at, ObPfPlan{});
+        if ((rc = ob_launch_status("decode_step_ksharded(attn)"))) return rc;
+        a.nproj = 1; a.K = (int)L.o.K;
+        if (st->k0_attn + L.o.K > NQ) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: o_proj slice of layer %d leaves the input vector", l);
+        if ((rc = ob_kshard_proj(a.p[0], L.o, st->z_o, H, NQ, "o_proj"))) return rc;
+        a.xin = (const _Float16 *)st->attn_out + st->k0_attn;
+        return ob_launch_dec_gemv(a, s);
+    }
+    case ONEBIT_KSEG_GATE_UP: {
+        na.hres_in = hB; na.hres_out = hA; na.z0 = st->z_o; na.g_prev = (const _Float16 *)L.o.weight_scale;
+        na.bias_prev = (const _Float16 *)L.o_bias;
+        na.rms_w = (const _Float16 *)L.post_attention_layernorm_w;
+        if (!na.g_prev) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
+        OB_LAUNCH_NORM(false, H, dim3(1), s, na);
+        if ((rc = ob_launch_status("decode_step_ksharded(norm2)"))) return rc;
+        a.nproj = 2; a.K = (int)L.gate.K;
+        if (L.up.K != L.gate.K || L.gate.K != L.q.K || st->k0_hidden + L.gate.K > H)
+            return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: gate / up slices of layer %d differ from q's or leave the input vector", l);
+        if ((rc = ob_kshard_proj(a.p[0], L.gate, st->z_gu, I, H, "gate_proj"))) return rc;
+        if ((rc = ob_kshard_proj(a.p[1], L.up, st->z_gu + I, I, H, "up_proj"))) return rc;
+        a.xin = (const _Float16 *)st->x + st->k0_hidden;
+        return ob_launch_dec_gemv(a, s);
+    }
+    default: {   // ONEBIT_KSEG_DOWN
+        ObBZgArgs za = {};
+        za.s[0] = {st->z_gu, (const _Float16 *)L.gate.weight_scale, (_Float16 *)st->u_gate, nullptr, I, 0};
+        za.s[1] = {st->z_gu + I, (const _Float16 *)L.up.weight_scale, (_Float16 *)st->u_up, nullptr, I, 0};
+        if (!L.gate.weight_scale || !L.up.weight_scale) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
+        if ((rc = launch_zg(za, 2))) return rc;
+        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr, nullptr};
+        OB_LAUNCH_SWIGLU(I, dim3(1), s, sa);
+        if ((rc = ob_launch_status("decode_step_ksharded(swiglu)"))) return rc;
+        a.nproj = 1; a.K = (int)L.down.K;
+        if (st->k0_inter + L.down.K > I) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: down_proj slice of layer %d leaves the input vector", l);
+        if ((rc = ob_kshard_proj(a.p[0], L.down, st->z_down, H, I, "down_proj"))) return rc;
+        a.xin = (const _Float16 *)st->act + st->k0_inter;
+        return ob_launch_dec_gemv(a, s);
+    }
+    }
 }
 
 // ------------------------------------------------------------ train-mode layer --

@@ -61,6 +61,18 @@ class _BatchState(ctypes.Structure):
                 ("x_scaled", _vp), ("chains", _i32)]
 
 
+class _KState(ctypes.Structure):      # onebit_kshard_state_t (ABI 8)
+    _fields_ = [("struct_size", ctypes.c_uint64), ("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
+                ("hres0", _vp), ("hres1", _vp), ("x", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp),
+                ("u_gate", _vp), ("u_up", _vp), ("act", _vp), ("u_down", _vp),
+                ("z_qkv", _vp), ("z_o", _vp), ("z_gu", _vp), ("z_down", _vp),
+                ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("tile_stats", _vp),
+                ("k0_hidden", _i32), ("k0_attn", _i32), ("k0_inter", _i32)]
+
+
+KSEG_QKV, KSEG_ATTN_O, KSEG_GATE_UP, KSEG_DOWN, KSEG_HEAD = 0, 1, 2, 3, 4
+
+
 class _FusedIn(ctypes.Structure):
     _fields_ = [("xin", _vp), ("embed", _vp), ("hres_in", _vp), ("u_prev", _vp), ("rms_w", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("token", _vp), ("hres_out", _vp),
@@ -112,7 +124,7 @@ def fp16_view(model: OneBitLlamaForCausalLM) -> OneBitLlamaForCausalLM:
     return copy.deepcopy(model, memo).half()
 
 
-def _proj(m: BitLinearInf, allow_bias: bool = False) -> _Proj:
+def _proj(m: BitLinearInf, allow_bias: bool = False, kslice=None) -> _Proj:
     if m.bias is not None and not allow_bias:
         raise ValueError(
             "the fused decode engines take a projection bias on q / k / v / o_proj only (config.attention_bias, "
@@ -127,13 +139,19 @@ def _proj(m: BitLinearInf, allow_bias: bool = False) -> _Proj:
     w = m.weight
     if w.stride(1) != 1 or not m.weight_scale.is_contiguous() or not m.input_factor.is_contiguous():
         raise ValueError("DecodeEngine: parameters must be contiguous")
+    if kslice is not None:
+        # the rank's K slice IN PLACE: a byte-column window of the packed matrix (the ABI takes the row pitch), h[k0:k1]
+        k0, k1 = kslice
+        return _Proj(w.data_ptr() + k0 // 8, m.input_factor.data_ptr() + 2 * k0, m.weight_scale.data_ptr(),
+                     m.out_features, k1 - k0, w.stride(0))
     return _Proj(w.data_ptr(), m.input_factor.data_ptr(), m.weight_scale.data_ptr(),
                  m.out_features, m.in_features, w.stride(0))
 
 
-def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int):
+def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int, krange=None):
     """ctypes image of ``onebit_model_t`` for ``model`` with per-layer (k, v) cache tensors; returns
-    (struct, objects that must stay alive as long as the struct is used)."""
+    (struct, objects that must stay alive as long as the struct is used).  ``krange(K) -> (k0, k1)``: describe every
+    projection's K SLICE instead (onebit_decode_step_ksharded: the rank's window into the full packed matrices)."""
     cfg = model.config
     p = model.lm_head.weight
     dev, f16 = p.device, torch.float16
@@ -149,8 +167,11 @@ def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int):
         if any(qkv_b) and not all(qkv_b):
             raise ValueError("the fused decode engines need a bias on all of q / k / v_proj or on none (config.attention_bias)")
         bptr = lambda p_: None if p_.bias is None else p_.bias.data_ptr()
-        layers[i] = _Layer(_proj(a.q_proj, True), _proj(a.k_proj, True), _proj(a.v_proj, True), _proj(a.o_proj, True),
-                           _proj(mlp.gate_proj), _proj(mlp.up_proj), _proj(mlp.down_proj),
+        ks = (lambda p_: None) if krange is None else (lambda p_: krange(p_.in_features))
+        layers[i] = _Layer(_proj(a.q_proj, True, ks(a.q_proj)), _proj(a.k_proj, True, ks(a.k_proj)), _proj(a.v_proj, True, ks(a.v_proj)),
+                           _proj(a.o_proj, True, ks(a.o_proj)),
+                           _proj(mlp.gate_proj, False, ks(mlp.gate_proj)), _proj(mlp.up_proj, False, ks(mlp.up_proj)),
+                           _proj(mlp.down_proj, False, ks(mlp.down_proj)),
                            layer.input_layernorm.weight.data_ptr(),
                            layer.post_attention_layernorm.weight.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                            bptr(a.q_proj), bptr(a.k_proj), bptr(a.v_proj), bptr(a.o_proj))

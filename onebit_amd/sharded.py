@@ -20,12 +20,12 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-__all__ = ["KShard", "shard_k", "k_sharded_forward", "hip_partial", "hip_epilogue", "KShardedBitLinear",
+__all__ = ["KShard", "shard_k", "k_sharded_forward", "hip_partial", "hip_epilogue", "KShardedBitLinear", "FusedKShardedDecoder", "lockstep_step",
            "shard_model_k", "NShard", "n_range", "shard_n", "n_sharded_forward", "hip_rows_u", "hip_row_stats", "hip_normalize"]
 
 
@@ -472,3 +472,206 @@ class StaticShapeDecoder:
                 self.graph = g
             self.graph.replay()
         self.steps += 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 4, fused (round 5): K-sharded single-stream decode as NATIVE segments + 4 collectives per layer.
+#
+# ``StaticShapeDecoder`` above replays the sharded MODULES (~15 launches per BitLinearInf-terminated op group, one
+# all-reduce per BitLinearInf: 280 collectives and ~600 launches per 13B token; 101 tok/s at N = 1 against 620 for the fused
+# single-GPU engine).  Here the step is ``onebit_decode_step_ksharded`` (include/onebit.h): per layer four segments of
+# native kernels -- the decode GEMV in its fp32-partial form on the rank's K slice (q|k|v and gate|up as ONE launch and ONE
+# fp32 buffer each), one-workgroup row kernels for the replicated glue, the decode attention kernel -- and between them ONE
+# all-reduce of the named buffer: 4 collectives and 10 launches per layer, all of it under one HIP graph.
+#
+#   z_qkv [NQ + 2 NK] -> all_reduce -> z_o [H] -> all_reduce -> z_gu [2 I] -> all_reduce -> z_down [H] -> all_reduce
+#
+# Slices are windows into the FULL packed matrices (no copy; boundaries on multiples of 128 columns = 16 bytes of a packed
+# row, the alignment of the decode kernels' 16-byte weight loads).  Everything that is not a K-sliced product is computed by
+# every rank from identical (all-reduced) inputs.  The segment backend is pluggable so that the exchange protocol -- which
+# buffer is reduced when, which columns a rank multiplies -- runs under gloo on CPU with a torch statement of the five
+# segments (tests/test_sharded_cpu.py); the product backend is the C ABI and nothing else.
+# ---------------------------------------------------------------------------------------------------
+class _HipSegments:
+    """The five segments through ``onebit_decode_step_ksharded`` (no CPU fallback)."""
+
+    def __init__(self, dec: "FusedKShardedDecoder"):
+        import ctypes
+        from . import _lib
+        from .engine import _KState, _Model, _model_struct, fp16_view
+        if not dec.dev.type == "cuda":
+            raise RuntimeError("FusedKShardedDecoder needs the model on a ROCm GPU (no CPU fallback)")
+        self._ct, self._lib_mod = ctypes, _lib
+        self.lib = _lib.load()
+        self.dec = dec
+        self._model, self._keep = _model_struct(dec.model, dec.cache.layers, dec.max_len, krange=dec.kr)
+        b = dec.buf
+        self.lib.onebit_decode_stats_floats.restype = ctypes.c_size_t
+        self.lib.onebit_decode_stats_floats.argtypes = [ctypes.POINTER(_Model)]
+        self._tile_stats = torch.zeros(max(int(self.lib.onebit_decode_stats_floats(ctypes.byref(self._model))), 1),
+                                       dtype=torch.float32, device=dec.dev)
+        p = lambda t: t.data_ptr()
+        self._state = _KState(ctypes.sizeof(_KState), p(dec.token), p(dec.pos), p(dec.out_tokens), dec.max_len,
+                              p(b["hres0"]), p(b["hres1"]), p(b["x"]), p(b["u_q"]), p(b["u_k"]), p(b["u_v"]), p(b["attn_out"]),
+                              p(b["u_gate"]), p(b["u_up"]), p(b["act"]), p(b["u_down"]),
+                              p(dec.z_qkv), p(dec.z_o), p(dec.z_gu), p(dec.z_down),
+                              p(b["logits"]), p(b["part_val"]), p(b["part_idx"]), p(self._tile_stats),
+                              dec.kr(dec.cfg.hidden_size)[0], dec.kr(dec.cfg.num_attention_heads * dec.cfg.head_dim)[0],
+                              dec.kr(dec.cfg.intermediate_size)[0])
+        self.lib.onebit_decode_step_ksharded.restype = ctypes.c_int
+        self.lib.onebit_decode_step_ksharded.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_KState), ctypes.c_int32, ctypes.c_int32,
+                                                         ctypes.c_void_p]
+
+    def segment(self, layer: int, seg: int):
+        dev = self.dec.dev
+        with torch.cuda.device(dev):
+            rc = self.lib.onebit_decode_step_ksharded(self._ct.byref(self._model), self._ct.byref(self._state), layer, seg,
+                                                      torch.cuda.current_stream(dev).cuda_stream)
+        self._lib_mod.check(rc, "onebit_decode_step_ksharded")
+
+
+class FusedKShardedDecoder:
+    """Greedy single-stream decode of ``model`` with every 1-bit projection's K dimension sharded over ``world`` ranks
+    (this process is ``rank``); ``model`` is the complete fp16 checkpoint on this rank's device -- the rank READS only its
+    column window of every packed matrix (1/world of the weight bytes per token).  ``group``: the process group of the K
+    shards (default: the world group when ``world`` > 1).  ``reduce_fn(t)``: replaces the all-reduce (tests drive several
+    ranks in one process).  ``backend(dec)``: an object with ``segment(layer, seg)`` (default: the C ABI).  ``granule``:
+    slice boundaries in columns (the C ABI needs 128; CPU stand-ins of the segments may use 32 on toy widths)."""
+
+    SEGMENTS = (0, 1, 2, 3)          # ONEBIT_KSEG_QKV, _ATTN_O, _GATE_UP, _DOWN; 4 = _HEAD once per token
+
+    def __init__(self, model: torch.nn.Module, rank: int, world: int, max_len: int, group=None, use_graph: bool = True,
+                 reduce_fn: Optional[Callable] = None, backend: Optional[Callable] = None, granule: int = 128):
+        from .llama import KVCache
+        cfg = model.config
+        p = model.lm_head.weight
+        if backend is None:
+            from .engine import fp16_view
+            model = fp16_view(model)
+            p = model.lm_head.weight
+        self.model, self.cfg, self.dev = model, cfg, p.device
+        self.rank, self.world, self.group = int(rank), int(world), group
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank outside the world")
+        self.max_len = int(max_len)
+        if self.max_len > cfg.max_position_embeddings:
+            raise ValueError("max_len exceeds max_position_embeddings")
+        H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        NQ, NK = cfg.num_attention_heads * D, cfg.num_key_value_heads * D
+        if backend is None and granule % 128:
+            raise ValueError("the HIP segments need slice boundaries on multiples of 128 columns (16-byte weight loads)")
+        for K in (H, NQ, I):
+            if K % granule or K // granule < self.world:
+                raise ValueError(f"in_features={K} cannot be split into {self.world} slices of whole {granule}-column granules")
+        self.kr = lambda K: k_range(K, self.rank, self.world, granule=granule)
+        dev, f16 = self.dev, p.dtype
+        z = lambda n, dt=f16: torch.zeros(n, dtype=dt, device=dev)
+        self.cache = KVCache(cfg, 1, self.max_len, dev, f16)
+        self.token, self.pos = z(1, torch.int32), z(1, torch.int32)
+        self.out_tokens = z(self.max_len, torch.int32)
+        self.buf = dict(hres0=z(H), hres1=z(H), x=z(H), u_q=z(NQ), u_k=z(NK), u_v=z(NK), attn_out=z(NQ), u_gate=z(I), u_up=z(I),
+                        act=z(I), u_down=z(H), logits=z(cfg.vocab_size), part_val=z(1024, torch.float32), part_idx=z(1024, torch.int32))
+        # the four exchanged buffers: fp32 partial sums out of a segment, complete sums into the next
+        self.z_qkv, self.z_o = z(NQ + 2 * NK, torch.float32), z(H, torch.float32)
+        self.z_gu, self.z_down = z(2 * I, torch.float32), z(H, torch.float32)
+        self.collectives_per_token = 4 * cfg.num_hidden_layers if self.world > 1 else 0
+        self._reduce_fn = reduce_fn
+        self.backend = _HipSegments(self) if backend is None else backend(self)
+        self.use_graph = bool(use_graph) and p.is_cuda
+        self.graph = None
+        self.steps = 0
+        self.first_token = None
+
+    # ---- one token -------------------------------------------------------------------------------
+    def _reduce(self, t: torch.Tensor):
+        if self._reduce_fn is not None:
+            self._reduce_fn(t)
+        elif self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _segments(self):
+        """Launch segment after segment; yields the buffer the caller has to all-reduce before the next one."""
+        for l in range(self.cfg.num_hidden_layers):
+            for seg, buf in zip(self.SEGMENTS, (self.z_qkv, self.z_o, self.z_gu, self.z_down)):
+                self.backend.segment(l, seg)
+                yield buf
+        self.backend.segment(0, 4)
+
+    def _step(self):
+        for buf in self._segments():
+            self._reduce(buf)
+
+    @torch.no_grad()
+    def prime(self, prompt: torch.Tensor) -> int:
+        """The prompt through the (replicated) module path into the KV cache; arms token / position."""
+        if prompt.dim() != 2 or prompt.shape[0] != 1:
+            raise ValueError("FusedKShardedDecoder is batch 1: prompt must be [1, S]")
+        S = prompt.shape[1]
+        if S + 1 > self.max_len:
+            raise ValueError("prompt longer than max_len")
+        self.cache.length = 0
+        logits = self.model(prompt.to(self.dev), self.cache)
+        self.token.copy_(logits[0, -1].argmax().to(torch.int32).reshape(1))
+        self.pos.fill_(S)
+        self.steps = self._prompt_len = S
+        self.first_token = int(self.token.item())
+        return self.first_token
+
+    def set_state(self, token: int, pos: int):
+        self.token.fill_(int(token)); self.pos.fill_(int(pos)); self.steps = int(pos)
+
+    @torch.no_grad()
+    def step(self):
+        if self.steps >= self.max_len:
+            raise RuntimeError("FusedKShardedDecoder: KV cache full")
+        if not self.use_graph:
+            self._step()
+        else:
+            if self.graph is None:
+                tok0, pos0 = self.token.clone(), self.pos.clone()
+                side = torch.cuda.Stream(self.dev)           # warm-up off the capture: function attributes, communicators
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    self._step()
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+                self.token.copy_(tok0); self.pos.copy_(pos0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step()
+                self.token.copy_(tok0); self.pos.copy_(pos0)
+                self.graph = g
+            self.graph.replay()
+        self.steps += 1
+
+    def logits(self) -> torch.Tensor:
+        return self.buf["logits"].float()
+
+    @torch.no_grad()
+    def generate(self, prompt: torch.Tensor, max_new_tokens: int) -> List[int]:
+        first = self.prime(prompt)
+        for _ in range(max(max_new_tokens - 1, 0)):
+            self.step()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        n = max(max_new_tokens - 1, 0)
+        return ([first] if max_new_tokens > 0 else []) + self.out_tokens[self._prompt_len:self._prompt_len + n].tolist()
+
+
+def lockstep_step(decoders) -> None:
+    """One token of several ``FusedKShardedDecoder`` ranks living in ONE process (tests): every rank's segment, then the
+    sum of the ranks' partial buffers written back to all of them -- what the all-reduce does, in rank order."""
+    gens = [d._segments() for d in decoders]
+    while True:
+        bufs = []
+        for g in gens:
+            try:
+                bufs.append(next(g))
+            except StopIteration:
+                pass
+        if not bufs:
+            break
+        total = torch.stack(bufs).sum(0)
+        for b in bufs:
+            b.copy_(total)
+    for d in decoders:
+        d.steps += 1

@@ -24,6 +24,8 @@ OBSERVED = {
     ("model_wide_e", "decode_logits"): (0.00781, 0.00745),       #   (gap 0.00600)
     ("model_wide_e", "batch_prefill"): (0.00586, 0.00766),       #   (gap 0.00651)
     ("model_wide_e", "batch_decode"): (0.00586, 0.00747),        #   (gap 0.00764)
+    ("model_wide_e", "kshard_decode"): (0.00684, 0.00680),       # FusedKShardedDecoder, worlds 1 / 2 / 4 / 8 in lockstep on one device
+    ("model_wide_c", "kshard_decode"): (0.00488, 0.00673),       #   worlds 3 / 8
 }
 
 

@@ -107,3 +107,83 @@ def test_shard_model_k_world1_13b_width():
         l0, l1 = ref(tok, c0), shd(tok, c1)
         assert float((l0.float() - l1.float()).abs().max()) <= 6e-3 * scale
         tok = l0[:, -1].argmax(-1, keepdim=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 5: the fused K-sharded decode step (onebit_decode_step_ksharded through FusedKShardedDecoder): native segments,
+# q|k|v and gate|up as one fp32 buffer each, 4 exchanges per layer.  N ranks are emulated on ONE device in lockstep (every
+# rank's segment, then the sum of the partial buffers written back to all of them: onebit_amd.sharded.lockstep_step) on
+# in-place slices of 13B-width and 7B-width layers, against logits recorded from the REFERENCE model
+# (tests/golden/model_wide_e.npz, model_wide_c.npz; teacher-forced with the reference's tokens).
+# ---------------------------------------------------------------------------------------------------
+def _wide_model(golden_dir, name):
+    import os
+    from onebit_amd.llama import OneBitLlamaConfig, OneBitLlamaForCausalLM, synthetic_state_dict
+    z = np.load(os.path.join(golden_dir, name))
+    kw = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg_")}
+    cfg = OneBitLlamaConfig(**kw)
+    model = OneBitLlamaForCausalLM(cfg, torch.float16)
+    model.load_state_dict(synthetic_state_dict(cfg, seed=int(z["seed"]), dtype=torch.float16, device="cpu"))
+    return z, cfg, model.to(torch.device("cuda:0")).eval()
+
+
+@pytest.mark.parametrize("fixture,world", [("model_wide_e", 1), ("model_wide_e", 2), ("model_wide_e", 4), ("model_wide_e", 8),
+                                           ("model_wide_c", 8), ("model_wide_c", 3)])
+def test_fused_k_sharded_decoder_vs_reference_logits(golden_dir, fixture, world):
+    from _parity_log import check, loose_tol
+    from onebit_amd.sharded import FusedKShardedDecoder, lockstep_step
+    z, cfg, model = _wide_model(golden_dir, fixture + ".npz")
+    dev = torch.device("cuda:0")
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    decs = [FusedKShardedDecoder(model, r, world, max_len=32, use_graph=False, reduce_fn=lambda t: None) for r in range(world)]
+    if world > 1:       # in-place windows: the ranks' slices tile every input vector, boundaries on 128 columns
+        for K in (cfg.hidden_size, cfg.intermediate_size):
+            edges = [d.kr(K) for d in decs]
+            assert edges[0][0] == 0 and edges[-1][1] == K and all(a[1] == b[0] and a[1] % 128 == 0 for a, b in zip(edges, edges[1:]))
+    toks = z["greedy_f16"][0]
+    for d in decs:
+        assert d.prime(ids) == int(toks[0])
+    ref16, ref32 = z["decode_logits_f16"], z["decode_logits_f32"]
+    for i in range(ref16.shape[1]):
+        for d in decs:
+            d.set_state(int(toks[i]), ids.shape[1] + i)                 # teacher-forced with the reference's tokens
+        lockstep_step(decs)
+        torch.cuda.synchronize()
+        lg = decs[0].logits().cpu().numpy()
+        check(fixture, "kshard_decode", f"FusedKShardedDecoder world={world} step {i}", lg, ref16[0, i], ref32[0, i], loose=loose_tol(ref16, ref32))
+        assert int(lg.argmax()) == int(toks[i + 1])
+        for d in decs[1:]:                                              # every rank: the same logits, token, position
+            assert torch.equal(d.buf["logits"], decs[0].buf["logits"]) and int(d.token.item()) == int(decs[0].token.item())
+            assert int(d.pos.item()) == ids.shape[1] + i + 1
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_fused_k_sharded_decoder_world1_equals_engine_tokens(golden_dir, use_graph):
+    """World 1 (what bench.py's decode_k_sharded runs per rank at N = 1), free-running under ONE HIP graph: the greedy tokens
+    of 10 steps equal the fused single-GPU engine's up to a near-tie, the logits stay within the reference bar of the step
+    they can be compared at; the segment call refuses a state of another ABI and a misaligned slice."""
+    import ctypes
+    from onebit_amd import _lib
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.sharded import FusedKShardedDecoder
+    z, cfg, model = _wide_model(golden_dir, "model_wide_e.npz")
+    dev = torch.device("cuda:0")
+    ids = torch.from_numpy(z["input_ids"]).to(dev)
+    eng = DecodeEngine(model, max_len=32)
+    ref = eng.generate(ids, 11)[0, ids.shape[1]:].tolist()
+    dec = FusedKShardedDecoder(model, 0, 1, max_len=32, use_graph=use_graph)
+    got = dec.generate(ids, 11)
+    assert dec.collectives_per_token == 0 and (dec.graph is not None) == use_graph
+    if got != ref:
+        j = next(i for i in range(len(ref)) if got[i] != ref[i])
+        lg = model(torch.tensor([ids[0].tolist() + ref[:j]], device=dev))[0, -1]
+        assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (j, got, ref)
+    st = dec.backend._state
+    st.struct_size -= 8
+    rc = dec.backend.lib.onebit_decode_step_ksharded(ctypes.byref(dec.backend._model), ctypes.byref(st), 0, 0, None)
+    assert rc == _lib.ERRORS["ARG"] if hasattr(_lib, "ERRORS") else rc != 0
+    st.struct_size += 8
+    st.k0_hidden = 64
+    rc = dec.backend.lib.onebit_decode_step_ksharded(ctypes.byref(dec.backend._model), ctypes.byref(st), 0, 0, None)
+    assert rc != 0 and b"128" in dec.backend.lib.onebit_last_error()
+    st.k0_hidden = 0
