@@ -323,6 +323,10 @@ typedef struct onebit_batch_state {
 size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);
 int onebit_decode_step_batched(const onebit_model_t *model, const onebit_batch_state_t *state, void *stream);
 
+/* Test support: fill all 160 KiB of LDS on every CU with `pattern` (LDS keeps its contents between launches); used by the
+ * GPU tests to show that no decode launch depends on stale zeros in the padded part of its LDS images.                  */
+int onebit_debug_fill_lds(uint32_t pattern, void *stream);
+
 /* ---- K-sharded decode step (BASELINE config 4: LLaMA-13B decode, hidden dim sharded over 2 / 4 / 8 GPUs) -------------
  * z = W+- . (h * x) is linear in K, so rank p keeps the byte-column slice W[:, K_p] of every packed
  * matrix and h[K_p], multiplies its slice and the fp32 partial sums of the ranks are added BEFORE the rounding points of

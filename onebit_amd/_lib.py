@@ -51,6 +51,8 @@ SYMBOLS = {
     "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),
     "onebit_decode_step": (_int, [_vp, _vp, _vp]),      # (onebit_model_t*, onebit_decode_state_t*, stream)
     "onebit_decode_step_batched": (_int, [_vp, _vp, _vp]),   # (onebit_model_t*, onebit_batch_state_t*, stream)
+    "onebit_decode_step_ksharded": (_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp]),   # (model*, onebit_kshard_state_t*, layer, segment, stream)
+    "onebit_debug_fill_lds": (_int, [ctypes.c_uint32, _vp]),
     "onebit_fused_gemv": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "onebit_train_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64, _int]),
     "onebit_train_forward": (_int, [_vp] * 8 + [_i64, _i64, _i64, _int, _f, _vp]),

@@ -33,6 +33,16 @@
 #define OB_SMFMA 1               // integer path: the digit sums S come from the matrix pipe (see the kernel); 0 = v_dot4 + DPP
 #endif
 
+// LDS layout of the integer-path decode GEMV, ONE statement for the kernel and for the host's launch size (they were two
+// hand-kept formulas): digit image [nproj][KV * waves * 512 elements][4 digit bytes] | cross-wave partials + wave scratch
+// (ob_dec_red_off floats) | 256 floats of reduction slots.
+__host__ __device__ constexpr int ob_dec_kq(int kv) { return kv * OB_DEC_WAVES * 512; }                      // elements of a wave row set
+__host__ __device__ constexpr int ob_dec_red_off(int mt) { return mt * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16; }
+__host__ __device__ constexpr size_t ob_dec_lds_i8_bytes(int nproj, int kv, int mt)
+{
+    return (size_t)nproj * ob_dec_kq(kv) * 4 + ((size_t)ob_dec_red_off(mt) + 256) * 4;
+}
+
 struct ObProj {
     const uint32_t *w;           // packed signs [N, ldw words]
     const _Float16 *h;           // input_factor [K]
@@ -537,10 +547,10 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_dec_gemv_kernel(const ObGem
     char *lds_q = smem;
     // integer path: the digit image covers ALL KV * 8 chunks of a wave row (chunks beyond K hold zero digits, written by the
     // wave that would own them), so the MFMA phase is one straight-line block with no per-chunk guard
-    constexpr int KQ = KV * OB_DEC_WAVES * 512;
+    constexpr int KQ = ob_dec_kq(KV);
     float *lds_red = reinterpret_cast<float *>(smem + (MATH == 1 ? (size_t)NPROJ * KQ * 4 : (size_t)NPROJ * Kpad * 2));
     // i8: lds_red holds [MT][8 waves][16 rows][4 digits] scaled fp32 partials
-    constexpr int RED_OFF = MATH == 1 ? (MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) : MT * OB_DEC_WAVES * 16;
+    constexpr int RED_OFF = MATH == 1 ? ob_dec_red_off(MT) : MT * OB_DEC_WAVES * 16;
     float *red = lds_red + RED_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gq = lane >> 4;

@@ -79,6 +79,26 @@ static inline void ob_set_max_lds_once(F kernel, bool (&done)[OB_MAX_DEVICES], i
 }
 
 extern "C" int onebit_abi_version(void) { return ONEBIT_ABI_VERSION; }
+
+static int ob_cu_count();
+// Test support: fill the LDS of every CU with `pattern` (LDS keeps its contents between launches).  The decode kernels multiply
+// digit images whose padding (chunks beyond K) must have been written by the launch itself; a test poisons the LDS first so that
+// a launch relying on stale zeros there produces garbage instead of passing by accident (advisor finding, round 4).
+__global__ __launch_bounds__(256) void ob_debug_fill_lds_kernel(uint32_t pattern, uint32_t *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *w = reinterpret_cast<uint32_t *>(smem);
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) w[i] = pattern;
+    __syncthreads();
+    if (sink && w[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern) *sink = 1;      // (keeps the stores)
+}
+extern "C" int onebit_debug_fill_lds(uint32_t pattern, void *stream)
+{
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_debug_fill_lds_kernel, attr_set, 160 * 1024);
+    hipLaunchKernelGGL(ob_debug_fill_lds_kernel, dim3(ob_cu_count() * 4), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, (uint32_t *)nullptr);
+    return ob_launch_status("debug_fill_lds");
+}
 extern "C" const char *onebit_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ packing --
@@ -775,7 +795,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
         int MSw;
         if (ob_dec_wgp_geometry(a, MSw, a.wg_end)) {
             const int Gw = a.wg_end[a.nproj - 1];
-            const size_t lds_w = (size_t)KV * OB_DEC_WAVES * 512 * 4 + ((size_t)MSw * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
+            const size_t lds_w = ob_dec_lds_i8_bytes(1, KV, MSw);        // (WGP: one projection per workgroup, MT = MS)
             bool hit = lds_w > 160 * 1024, ok = false;        // (cannot happen for K <= 8192; then the per-slot form below)
 #define OB_WCASE(P, M) if (!hit && KV == P && MSw == M) { hit = true; ok = ob_launch_dec_gemv_wgp<P, M>(a, Gw, lds_w, s); }
             OB_WCASE(1, 1) OB_WCASE(1, 2) OB_WCASE(1, 3) OB_WCASE(1, 4) OB_WCASE(1, 5) OB_WCASE(1, 6) OB_WCASE(1, 7) OB_WCASE(1, 8)
@@ -794,7 +814,7 @@ static int ob_launch_dec_gemv(const ObGemvArgs &a_in, hipStream_t s)
         return ob_fail(ONEBIT_E_SHAPE, "decode gemv: in_features > 4096 needs K %% 128 == 0 and 16-byte aligned rows");
     const int MT = MS * a.nproj;
     // (integer path: the digit image covers all KV * 8 chunks of a wave row, ob_decode.h)
-    const size_t lds_i8 = (size_t)a.nproj * KV * OB_DEC_WAVES * 512 * 4 + ((size_t)MT * OB_DEC_WAVES * 64 + 3 * OB_DEC_WAVES * 16 + 16) * 4 + 256 * 4;
+    const size_t lds_i8 = ob_dec_lds_i8_bytes(a.nproj, KV, MT);
     // the integer path pays a per-projection quantisation; with one 512-weight chunk per wave it does not pay back
     // single-chunk launches (o_proj: one tile, one 512-weight chunk per wave) take the integer path as well since round 4
     // (8 MFMAs + 32 v_and instead of 16 MFMAs + 227 sign-expansion instructions: 3.54 -> 3.07 us per launch in a chain;

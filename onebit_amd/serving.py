@@ -109,6 +109,19 @@ class Scheduler:
             n = 0                                                             # whole prompts only
         return max(n, 0)
 
+    def head_admissible(self) -> bool:
+        """Would the NEXT plan() admit the head of the waiting queue?  (A free slot is not enough: under ``max_step_tokens`` the
+        prompt -- or, with ``prefill_chunk``, its first chunk -- must fit next to the running requests' decode tokens.)"""
+        if not self.waiting or not self._free:
+            return False
+        budget = None
+        if self.max_step_tokens is not None:
+            budget = self.max_step_tokens - sum(1 for r in self.running if r.pos >= len(r.prompt))
+            for r in self.running:                                            # prompts still entering go first, as in plan()
+                if r.pos < len(r.prompt):
+                    budget -= self._chunk(r, budget)
+        return self._chunk(self.waiting[0], budget) > 0
+
     def plan(self) -> List[Item]:
         items = [Item(r, [r.out[-1]], r.pos) for r in self.running if r.pos >= len(r.prompt)]   # decode tokens first
         budget = None if self.max_step_tokens is None else self.max_step_tokens - len(items)
@@ -279,7 +292,7 @@ class ContinuousBatcher:
         of the step finishes (or reaches the end of its cache slot) before the last of them."""
         if self._native is None or self._native.next_tokens is None or not self.use_graph or self.max_burst <= 1:
             return 1
-        if self.sched.waiting and self.sched._free:
+        if self.sched.head_admissible():         # (a waiting request that max_step_tokens keeps out does not end the burst)
             return 1
         if len(items) != len(self.sched.running):
             return 1
@@ -302,6 +315,9 @@ class ContinuousBatcher:
         assert first is None
         self._g_ring[0].copy_(self._g_next, non_blocking=True)
         if self._graph_fb is None:
+            # the warm-up below runs one feedback step on the LIVE state and rewinds it: it writes KV row start + 1 of every
+            # slot, which the replay rewrites identically -- provided that row exists and the burst does replay it
+            assert n >= 2 and max(it.start for it in items) + 1 < self.sched.max_len, "burst warm-up outside the cache slot"
             tok0, pos0, nxt0 = self._native.tokens.clone(), self._native.pos.clone(), self._native.next_tokens.clone()
             torch.cuda.synchronize(self.dev)
             self._feedback_static()                                  # warm-up on the live state ...

@@ -370,3 +370,42 @@ def test_gemm_epilogue_tile_stats_equal_row_stats(T, K, N, prescaled):
         u2, st2 = hip_rows_u_stats(sh2, a, prescaled=prescaled)
         assert torch.equal(u2, u_ref[:, :1376])
         np.testing.assert_allclose(st2.cpu().numpy(), hip_row_stats(u2).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("K,N,nproj", [(11008, 4096, 1), (5120, 5120, 3), (4096, 11008, 2), (13824, 5120, 1), (640, 5120, 3)])
+@pytest.mark.parametrize("pattern", [0x7FFF7FFF, 0x7C007C00])
+def test_decode_gemv_does_not_depend_on_stale_lds(coracle, K, N, nproj, pattern):
+    """The integer-path decode GEMV multiplies a digit image that covers ALL KV * 8 chunks of a wave row; the chunks beyond K
+    (K = 11008: 21.5 of 24, K = 5120: 10 of 16, K = 640: 1.25 of 8) must have been written as zeros by THIS launch, and
+    ob_dec_load_w no longer zeroes the packed words it re-reads there (round 4) -- so a stale LDS region would be multiplied by
+    real weight bits.  LDS keeps its contents between launches: poison all 160 KiB of every CU with fp16 NaN / Inf bit patterns
+    (0x7FFF.. as int8 digits: 127 / -1), then run the launch and hold it to the oracle as usual (advisor finding, round 4)."""
+    from onebit_amd import _lib
+    from onebit_amd.bitnet import _stream_ptr
+    from onebit_amd.engine import PRO_PLAIN, PRO_RES_LN_RMS, fused_gemv
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    mods = [_mk(K, N, 300 + i + K // 128, dev) for i in range(nproj)]
+    rng = np.random.default_rng(K + nproj)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    outs = [torch.empty(N, dtype=torch.float16, device=dev) for _ in range(nproj)]
+    if nproj == 1:
+        x = rng.standard_normal(K).astype(np.float16)
+        _lib.check(lib.onebit_debug_fill_lds(pattern, _stream_ptr(dev)), "fill_lds")
+        fused_gemv([mods[0][0]], outs, PRO_PLAIN, xin=t(x))
+        xn = x
+    else:
+        hres = rng.standard_normal(K).astype(np.float16)
+        u_prev = rng.standard_normal(K).astype(np.float16)
+        rms_w = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+        hout = torch.empty(K, dtype=torch.float16, device=dev)
+        _lib.check(lib.onebit_debug_fill_lds(pattern, _stream_ptr(dev)), "fill_lds")
+        fused_gemv([m[0] for m in mods], outs, PRO_RES_LN_RMS, hres_in=t(hres), u_prev=t(u_prev), hres_out=hout, rms_w=t(rms_w))
+        hk = hout.cpu().numpy().astype(np.float32)
+        rs = 1.0 / np.sqrt((hk.astype(np.float64) ** 2).mean() + 1e-6)
+        xn = (rms_w * (hk * rs).astype(np.float16)).astype(np.float16)
+    for (m, w, h, g), o in zip(mods, outs):
+        _, ref = coracle.forward_f16(w, xn[None], h, g, None, return_pre_ln=True)
+        got = o.cpu().numpy()
+        assert np.isfinite(got.astype(np.float32)).all()
+        _check_u(got, ref[0], "K=%d N=%d nproj=%d pattern=%x" % (K, N, nproj, pattern), frac=0.03)

@@ -104,3 +104,28 @@ def test_scheduler_rejects_budgets_that_cannot_progress():
         steps += 1
         assert steps < 200
     assert len(s.finished) == 5
+
+
+def test_head_admissible_agrees_with_plan():
+    """`head_admissible` (what ends a host-free decode burst, serving.py `_burst_len`) is exactly "the next plan() admits the head
+    of the queue": a free slot alone does not make a request admissible under max_step_tokens (advisor finding, round 4)."""
+    s = Scheduler(max_batch=4, max_len=64, max_step_tokens=8)
+    a = s.add(list(range(6)), 4)
+    assert s.head_admissible()
+    items = s.plan()
+    s.commit(items, [1] * len(items))
+    b = s.add(list(range(8)), 2)                  # 8 prompt tokens + 1 running decode token > 8: blocked although 3 slots are free
+    assert s._free and s.waiting and not s.head_admissible()
+    items = s.plan()
+    assert [it.req.rid for it in items] == [a]
+    s.commit(items, [1])
+    c = Scheduler(max_batch=2, max_len=64, max_step_tokens=4, prefill_chunk=3)
+    c.add(list(range(7)), 2)
+    c.add(list(range(5)), 2)
+    for _ in range(6):                            # every step: the prediction equals what plan() then does
+        n_wait = len(c.waiting)
+        pred = c.head_admissible()
+        items = c.plan()
+        assert pred == (len(c.waiting) < n_wait)
+        c.commit(items, [1] * len(items))
+    assert not Scheduler(max_batch=1, max_len=8).head_admissible()       # nothing waiting
