@@ -35,8 +35,8 @@
 //     fragments of the first 32 keys requested before the softmax arithmetic)
 // What bounds it now (ablations in flash_lab: no softmax arithmetic 755, no staging 821, neither 1039 TFLOP/s): the softmax VALU
 // work and the K / V staging of a wave run in series with its MFMAs, and the second wave of the SIMD covers little of it.  Three
-// rearrangements meant to force the overlap were built, are correct, and measured SLOWER; they are kept under tools/attic with
-// their numbers: one wave per SIMD with 64 queries per wave and hand-interleaved softmax (565; ob_flash64_experiment.h), an
+// rearrangements meant to force the overlap were built, are correct, and measured SLOWER; their numbers are in
+// docs/experiments.md, their code in the git history (tools/attic, removed in round 5): one wave per SIMD with 64 queries per wave and hand-interleaved softmax (565; ob_flash64_experiment.h), an
 // 8-wave ping-pong where one wave of a SIMD streams MFMAs while its partner does only VALU work (599; ob_flash_pp.h -- its
 // ablations show MFMA-phase time + softmax-phase time ~ total time, although pure MFMA and VALU streams of two waves do overlap
 // on this SIMD: tools/pipe_overlap_probe.hip, profiles/r04_pipe_overlap_probe.txt), and

@@ -4,19 +4,14 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ionebit_amd/csrc -Itools [-DOB_FL_...] tools/flash_lab.hip -o tools/flash_lab
 //   tools/flash_lab [B S H reps label]          (FL_DYN=40000 in the environment: one workgroup per CU)
 // -DOB_FL_ABL=1|2|3: no softmax arithmetic / no staging / neither (timing only); -DOB_FL_DEFER_THR=0.0f: rescale on every new maximum;
-// -DFL_K64 / -DFL_PP: the experiments under tools/attic instead of the product kernel
+// (the -DFL_K64 / -DFL_PP builds of rounds 3-4 ran the rejected rearrangements that lived under tools/attic: removed in round 5,
+//  results in docs/experiments.md "Prefill attention, round 4", code in the git history)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include "ob_flash.h"
-#ifdef FL_K64
-#include "attic/ob_flash64_experiment.h"
-#endif
-#ifdef FL_PP
-#include "attic/ob_flash_pp.h"
-#endif
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static inline float rnd_uniform()
@@ -42,22 +37,10 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dk, k.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(dv, v.data(), 2 * n, hipMemcpyHostToDevice));
     CK(hipMemset(d_o, 0, 2 * n));
-#if defined(FL_PP)
-#define FL_KERNEL ob_flash_pp_kernel<D>
-#define FL_THREADS OB_FLPP_THREADS
-    const int nmb = (S + OB_FLPP_BM - 1) / OB_FLPP_BM;
-    const int dyn0 = OB_FLPP_LDS;
-#elif defined(FL_K64)
-#define FL_THREADS OB_FL_THREADS
-#define FL_KERNEL ob_flash_fwd64_kernel<D>
-    const int nmb = (S + OB_FL64_BM - 1) / OB_FL64_BM;
-    const int dyn0 = OB_FL64_LDS;
-#else
 #define FL_THREADS OB_FL_THREADS
 #define FL_KERNEL ob_flash_fwd_kernel<D>
     const int nmb = (S + OB_FL_BM - 1) / OB_FL_BM;
     const int dyn0 = 0;
-#endif
     ObFlashArgs a = {dq, dk, dv, d_o, nullptr, S, H, H, S, 0, 1.4426950408889634f / sqrtf((float)D), nmb};
 #ifdef OB_FL_TRACE
     unsigned long long *dtr;
