@@ -6,10 +6,11 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import csrc_sha
-# template arguments: KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP (round 4: q|k|v and gate|up are one-projection-per-workgroup
+# template arguments: KV, MS, ALIGNED, PRO, MATH, NPROJ, PST, WGP, BIAS, ZOUT (round 4: q|k|v and gate|up are one-projection-per-workgroup
 # launches, o_proj runs on the integer path)
-names = {"<1, 4, true, 2, 1, 1, true, true>": "qkv", "<1, 1, true, 0, 1, 1, false, false>": "o", "<1, 6, true, 2, 1, 1, true, true>": "gate_up",
-         "<3, 1, true, 3, 1, 1, true, false>": "down"}
+# round 5: two more template arguments (BIAS, ZOUT), both false in the product step of a bias-free checkpoint
+names = {"<1, 4, true, 2, 1, 1, true, true, false, false>": "qkv", "<1, 1, true, 0, 1, 1, false, false, false, false>": "o",
+         "<1, 6, true, 2, 1, 1, true, true, false, false>": "gate_up", "<3, 1, true, 3, 1, 1, true, false, false, false>": "down"}
 out = {}
 for line in open(sys.argv[1]):
     m = re.search(r"FETCH_SIZE avg ([0-9.]+)", line)
