@@ -16,8 +16,6 @@ struct ObBNormArgs {
     const _Float16 *u_prev;       // !EMBED: [B, H] pre-LayerNorm output of the previous projection, or NULL with
     const float *z0, *z1;         //   fp32 split-K partial sums [B, H] of it (u = fp16(fp16(z0 + z1) * g_prev))
     const _Float16 *g_prev;       //   and its weight_scale [H]
-    const _Float16 *bias_prev;    // optional [H]: bias of the projection that produced u_prev (o_proj with config.attention_bias):
-                                  //   r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120, then :912)
     const _Float16 *rms_w;        // [H]
     _Float16 *hres_out;           // [B, H]
     _Float16 *x;                  // [B, H] (may be NULL when only the scaled outputs are wanted)
@@ -30,6 +28,9 @@ struct ObBNormArgs {
     int n_scaled;
     ObPfPlan pf;                  // optional (nseg > 0): packed rows of the next GEMM launch to pull into L2 (ob_common.h) --
     int pf_rows;                  //   by the workgroups beyond the first pf_rows (= rows) of the grid, which do nothing else
+    // (appended in round 5: the fields above keep their kernarg offsets)
+    const _Float16 *bias_prev;    // optional [H]: bias of the projection that produced u_prev (o_proj with config.attention_bias):
+                                  //   r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120, then :912)
 };
 
 // NV = 8-half vectors per thread actually populated: ceil(H / 4096).  (Sized OB_DEC_MAXV = 4 for every width, a 4096-wide

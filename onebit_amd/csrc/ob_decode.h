@@ -73,9 +73,6 @@ struct ObGemvArgs {
     // workgroup barrier.  Buffers hold a multiple of 256 tiles (reads beyond K/16 are masked).
     const float *st_prev, *st_gate, *st_up;
     float rms_eps, ln_eps;
-    // RES_LN_RMS, BIAS kernels: bias [K] of the projection that produced u_prev (o_proj with config.attention_bias,
-    // modeling_bitllama.py:454): r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120 then :912)
-    const _Float16 *bias_prev;
     // WGP kernels (one projection per workgroup): workgroups [wg_end[p-1], wg_end[p]) own the tiles of projection p
     int wg_end[3];
     // EMBED_RMS (first launch of a step), optional: workgroup 0 copies the rotary rows of the current position,
@@ -84,9 +81,14 @@ struct ObGemvArgs {
     const _Float16 *rope_cos, *rope_sin;
     _Float16 *rope_out;
     int rope_D, rope_max;
-    int zout;                      // host-side selector of the ZOUT instances (fp32 partial sums of a K slice to ObProj.u); PLAIN only
     int ablate;                    // profiling builds only (-DOB_PROFILE_ABLATE + OB_ABLATE env); 0 = normal
     unsigned long long *dbg;       // profiling builds only: per-workgroup phase timestamps [grid][8]
+    // ---- round 5, appended so that every field above keeps its kernarg offset (8 bytes more in the MIDDLE of this struct cost
+    //      the layer-order chain 0.37 us per layer: profiles/r05_bench.json vs the same day's baseline) ----
+    // RES_LN_RMS, BIAS kernels: bias [K] of the projection that produced u_prev (o_proj with config.attention_bias,
+    // modeling_bitllama.py:454): r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120 then :912)
+    const _Float16 *bias_prev;
+    int zout;                      // host-side selector of the ZOUT instances (fp32 partial sums of a K slice to ObProj.u); PLAIN only
 };
 
 // Block-wide sums of NV values through LDS.  `red` must be a slot (16*NV floats, 16-byte aligned)
