@@ -13,6 +13,7 @@
 //   mode 3  write-through payload + one flag granule per producer; wave 0 polls the flags, then everyone loads the payload
 //   mode 4  granules as mode 0, but wave 0 first polls ONE granule per producer (2 KB per round instead of the vector)
 //   mode 9  the same skeleton as 160 dependent LAUNCHES in a hipGraph (plain stores / plain loads): the baseline
+//   hybrid  [q|k|v -> attention -> o] as one launch with mode-0 hand-offs on its two SUBSET edges, gate|up and down as launches
 // Every value is checked (hash of layer, phase, index); every spin is bounded.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o persist_probe tools/persist_probe.hip && ./persist_probe
 #include <hip/hip_runtime.h>
@@ -336,35 +337,50 @@ __global__ __launch_bounds__(NTH) void persist_kernel(const Params P)
 }
 
 // ---- mode 9: the same phase as its own launch (plain stores, plain loads after the kernel boundary) -----------------------------
+__device__ __forceinline__ u32 consume_plain(const Params &P, int lp, int pp, int b, int tid)
+{
+    const PhaseDesc &S = P.ph[pp];
+    if (b < S.cons_first || b >= S.cons_first + S.cons_n) return 0;
+    const u32 *pv = P.plain + (lp & 1) * P.plain_stride + P.goff[pp] * 2, *ps = P.plain + (lp & 1) * P.plain_stride + P.soff[pp] * 2;
+    int nval = S.prod_n * S.gpp, off = 0;
+    const int nst = S.prod_n * S.spp;
+    if (S.subset > 0) { off = (b - S.cons_first) * S.subset; nval = S.subset; }
+    u32 v[MAXV], sv[8], bad = 0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+        if (k * NTH < nval) v[k] = pv[off + min(k * NTH + tid, nval - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k * NTH < nst) sv[k] = ps[min(k * NTH + tid, nst - 1)];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+        if (k * NTH < nval && k * NTH + tid < nval) bad += v[k] != val_of(lp, pp, off + k * NTH + tid);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k * NTH < nst && k * NTH + tid < nst) bad += sv[k] != val_of(lp, pp, 0x100000 + k * NTH + tid);
+    return bad;
+}
+__device__ __forceinline__ void produce_plain(const Params &P, int l, int p, int b, int tid)
+{
+    const PhaseDesc &D = P.ph[p];
+    if (b < D.prod_first || b >= D.prod_first + D.prod_n) return;
+    const int j = b - D.prod_first;
+    u32 *pv = P.plain + (l & 1) * P.plain_stride + P.goff[p] * 2, *ps = P.plain + (l & 1) * P.plain_stride + P.soff[p] * 2;
+    if (tid < D.gpp) pv[j * D.gpp + tid] = val_of(l, p, j * D.gpp + tid);
+    else if (tid < D.gpp + D.spp) ps[j * D.spp + (tid - D.gpp)] = val_of(l, p, 0x100000 + j * D.spp + (tid - D.gpp));
+}
+
 __global__ __launch_bounds__(NTH) void launch_kernel(const Params P, int l, int p)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     const PhaseDesc &D = P.ph[p];
-    u32 bad = 0;
     float x = (float)tid;
     u32 acc = 0;
     const bool prod = b >= D.prod_first && b < D.prod_first + D.prod_n;
-    // input = output of the previous phase
     const int pp = p == 0 ? 4 : p - 1, lp = p == 0 ? l - 1 : l;
-    u32 v[MAXV];
-    u32 sv[8];
-    int nval = 0, nst = 0, off = 0;
-    bool cons = false;
-    if (lp >= 0) {
-        const PhaseDesc &S = P.ph[pp];
-        cons = b >= S.cons_first && b < S.cons_first + S.cons_n;
-        const u32 *pv = P.plain + (lp & 1) * P.plain_stride + P.goff[pp] * 2, *ps = P.plain + (lp & 1) * P.plain_stride + P.soff[pp] * 2;
-        nval = S.prod_n * S.gpp; nst = S.prod_n * S.spp;
-        if (S.subset > 0) { off = ((b - S.cons_first) * S.subset) % max(nval - S.subset + 1, 1); nval = S.subset; }
-        if (cons) {
-#pragma unroll
-            for (int k = 0; k < MAXV; ++k)
-                if (k * NTH < nval) v[k] = pv[off + min(k * NTH + tid, nval - 1)];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k * NTH < nst) sv[k] = ps[min(k * NTH + tid, nst - 1)];
-        }
-    }
+    // input vectors first (the wait for them must not include the weight stream: the decode kernels' counted waits), then the
+    // weight requests, which return underneath the arithmetic
+    u32 bad = lp >= 0 ? consume_plain(P, lp, pp, b, tid) : 0;
     u32x4 w[6];
     const int slot0 = p == 0 ? 0 : (p == 2 ? 4 : (p == 3 ? 5 : 11));
     if (P.use_weights && prod && D.wloads > 0) {
@@ -373,14 +389,6 @@ __global__ __launch_bounds__(NTH) void launch_kernel(const Params P, int l, int 
         for (int i = 0; i < 6; ++i)
             if (i < D.wloads) w[i] = __builtin_nontemporal_load(base + (size_t)i * NTH);
     }
-    if (cons) {
-#pragma unroll
-        for (int k = 0; k < MAXV; ++k)
-            if (k * NTH < nval && k * NTH + tid < nval) bad += v[k] != val_of(lp, pp, off + k * NTH + tid);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k * NTH < nst && k * NTH + tid < nst) bad += sv[k] != val_of(lp, pp, 0x100000 + k * NTH + tid);
-    }
     __syncthreads();
     if (P.compute && prod) x = fake_math(x, D.iters);
     if (P.use_weights && prod && D.wloads > 0) {
@@ -388,12 +396,39 @@ __global__ __launch_bounds__(NTH) void launch_kernel(const Params P, int l, int 
         for (int i = 0; i < 6; ++i)
             if (i < D.wloads) acc ^= w[i][0] ^ w[i][1] ^ w[i][2] ^ w[i][3];
     }
-    if (prod) {
-        const int j = b - D.prod_first;
-        u32 *pv = P.plain + (l & 1) * P.plain_stride + P.goff[p] * 2, *ps = P.plain + (l & 1) * P.plain_stride + P.soff[p] * 2;
-        if (tid < D.gpp) pv[j * D.gpp + tid] = val_of(l, p, j * D.gpp + tid);
-        else if (tid < D.gpp + D.spp) ps[j * D.spp + (tid - D.gpp)] = val_of(l, p, 0x100000 + j * D.spp + (tid - D.gpp));
-    }
+    produce_plain(P, l, p, b, tid);
+    if (bad) atomicAdd(P.err, bad);
+    if (x == 12345.678f || acc == 0x12345678u) P.sink[0] = acc + (u32)x;
+}
+
+// ---- hybrid: q|k|v -> attention -> o as ONE launch (the two SUBSET edges in-launch: 192 producers -> 32 attention workgroups,
+// 32 -> 256), the three big all-to-all edges (o -> gate|up -> down -> next layer) stay kernel boundaries.  o_proj's rows are
+// requested at kernel entry (in flight under q|k|v and the attention).  Three launches per layer instead of five.
+__global__ __launch_bounds__(NTH) void hybrid_kernel(const Params P, int l)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32 *lds_vals = reinterpret_cast<u32 *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    WaveState ws = {false, 0};
+    float x = (float)tid;
+    u32 acc = 0;
+    const bool in0 = b < P.ph[0].prod_n;
+    const bool attn = b >= P.ph[1].prod_first && b < P.ph[1].prod_first + P.ph[1].prod_n;
+    u32 bad = l > 0 ? consume_plain(P, l - 1, 4, b, tid) : 0;
+    u32x4 w0[4], w2[1];
+    if (P.use_weights) { if (in0) wload(w0, P, l, b, 0, tid); wload(w2, P, l, b, 4, tid); }
+    __syncthreads();
+    if (P.compute && in0) x = fake_math(x, P.ph[0].iters);
+    if (P.use_weights && in0) acc ^= wuse(w0);
+    produce<0>(P, l, 0, b, tid);
+    consume<0>(P, l, 0, b, tid, lds_vals, ws);
+    if (P.compute && attn) x = fake_math(x, P.ph[1].iters);
+    produce<0>(P, l, 1, b, tid);
+    consume<0>(P, l, 1, b, tid, lds_vals, ws);
+    if (P.compute) x = fake_math(x, P.ph[2].iters);
+    if (P.use_weights) acc ^= wuse(w2);
+    produce_plain(P, l, 2, b, tid);
+    bad += ws.bad;
     if (bad) atomicAdd(P.err, bad);
     if (x == 12345.678f || acc == 0x12345678u) P.sink[0] = acc + (u32)x;
 }
@@ -517,6 +552,38 @@ int main(int argc, char **argv)
         return med;
     };
 
+    auto run_hybrid = [&](int use_w, int compute) -> double {
+        Params Q = P; Q.use_weights = use_w; Q.compute = compute;
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int par = 0; par < 2; ++par) CK(hipMemsetAsync(Q.gran[par], 0, ngran * 8, s));       // granule tags: once per token
+        for (int l = 0; l < layers; ++l) {
+            hipLaunchKernelGGL(hybrid_kernel, dim3(G), dim3(NTH), 60 * 1024, s, Q, l);
+            hipLaunchKernelGGL(launch_kernel, dim3(G), dim3(NTH), 0, s, Q, l, 3);
+            hipLaunchKernelGGL(launch_kernel, dim3(G), dim3(NTH), 0, s, Q, l, 4);
+        }
+        CK(hipStreamEndCapture(s, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        std::vector<double> t;
+        u32 errs[2] = {0, 0};
+        for (int r = 0; r < reps + 2; ++r) {
+            CK(hipMemsetAsync(Q.err, 0, 8, s));
+            CK(hipEventRecord(e0, s));
+            CK(hipGraphLaunch(exec, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) t.push_back(ms * 1e3);
+            u32 e[2]; CK(hipMemcpy(e, Q.err, 8, hipMemcpyDeviceToHost));
+            errs[0] += e[0]; errs[1] += e[1];
+            if (e[1]) break;
+        }
+        const double med = t.empty() ? -1.0 : median(t);
+        printf("hybrid    (3 launches per layer: [q|k|v -> attention -> o] in-launch, gate|up, down) weights %d math %d: %8.1f us = %6.2f us per layer (min %.1f)  "
+               "wrong values %u, timeouts %u\n", use_w, compute, med, med / layers, t.empty() ? -1.0 : *std::min_element(t.begin(), t.end()), errs[0], errs[1]);
+        CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+        return med;
+    };
     double sum_math = 0;
     for (int p = 0; p < NPH; ++p) { P.ph[p].iters = (int)(math_us[p] * 100.0); sum_math += math_us[p]; }      // 100 MHz ticks
     printf("simulated arithmetic per layer: %.1f us (q|k|v %.1f, attention %.1f, o %.1f, gate|up %.1f, down %.1f), a wall-clock wait\n", sum_math, math_us[0],
@@ -524,15 +591,19 @@ int main(int argc, char **argv)
 
     printf("\n== floor: hand-offs only ==\n");
     run_launches(0, 0);
+    run_hybrid(0, 0);
     for (int mode : {0, 1, 3, 4}) run_persist(mode, 0, 0, true);
     printf("\n== hand-offs + weight stream ==\n");
     run_launches(1, 0);
+    run_hybrid(1, 0);
     for (int mode : {0, 1, 3, 4}) run_persist(mode, 1, 0, true);
     printf("\n== hand-offs + weight stream + simulated arithmetic ==\n");
     run_launches(1, 1);
+    run_hybrid(1, 1);
     for (int mode : {0, 1, 3, 4}) run_persist(mode, 1, 1, true);
     printf("\n== arithmetic only (no weights) ==\n");
     run_launches(0, 1);
+    run_hybrid(0, 1);
     for (int mode : {0, 1, 3, 4}) run_persist(mode, 0, 1, false);
     return 0;
 }
