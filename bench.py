@@ -368,7 +368,7 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
         out["fused"] = {"ms_per_token": round(dt / steps * 1e3, 4), "tokens_per_s": round(steps / dt, 1),
                         "path": "FusedKShardedDecoder: onebit_decode_step_ksharded segments (decode GEMV in fp32-partial form on the rank's "
                                 "K slice, row kernels, decode attention) + all_reduce(fp32) replayed as one HIP graph",
-                        "collectives_per_token": fdec.collectives_per_token, "launches_per_token": 10 * L + 3,
+                        "collectives_per_token": fdec.collectives_per_token, "launches_per_token": 8 * L + 3,
                         "reduced_fp32_bytes_per_token": 4 * L * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim
                                                                  + 2 * cfg.hidden_size + 2 * cfg.intermediate_size) if world > 1 else 0}
         del fdec

@@ -340,8 +340,9 @@ int onebit_debug_fill_lds(uint32_t pattern, void *stream);
  *   then once:           segment ONEBIT_KSEG_HEAD     (final norm, fp16 lm_head, greedy token, position += 1)
  *
  * = 4 collectives per layer instead of one per BitLinearInf call (7), every launch a native kernel (the decode GEMV in its
- * fp32-partial form on the rank's K slice, one-workgroup row kernels for the replicated glue, the decode attention kernel;
- * 10 launches per layer), capturable with the collectives in ONE HIP graph.  Everything that is not a K-sliced product
+ * fp32-partial form on the rank's K slice, one-workgroup row kernels for the replicated glue, the decode attention kernel --
+ * the consumers of a reduced sum round and scale it themselves: 8 launches per layer), capturable with the collectives in ONE
+ * HIP graph.  Everything that is not a K-sliced product
  * (LayerNorm / RMSNorm / RoPE / attention over the replicated KV cache / lm_head) is computed by every rank on identical
  * inputs, hence identical results.  world = 1: no collective, the same arithmetic.
  *
@@ -356,7 +357,7 @@ typedef struct onebit_kshard_state {
     int32_t max_out;
     void *hres0, *hres1;        /* fp16 [hidden] residual stream ping-pong                                           */
     void *x;                    /* fp16 [hidden] normalised input of the next projections                            */
-    void *u_q, *u_k, *u_v;      /* fp16 [n_heads*D], [n_kv*D] x 2: fp16(fp16(z) * g) of the reduced sums              */
+    void *u_q, *u_k, *u_v;      /* fp16 [n_heads*D], [n_kv*D] x 2: scratch (unused since the consumers read z directly) */
     void *attn_out;             /* fp16 [n_heads*D]                                                                   */
     void *u_gate, *u_up, *act;  /* fp16 [intermediate] x 3                                                           */
     void *u_down;               /* fp16 [hidden]                                                                      */

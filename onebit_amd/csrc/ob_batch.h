@@ -174,6 +174,10 @@ struct ObBSwigluArgs {
                                      // column slice (tensor-parallel N-shard), their statistics were combined across ranks
     ObPfPlan pf;                     // optional (nseg > 0): packed rows of the next GEMM launch to pull into L2, by the
     int pf_rows;                     //   workgroups beyond the first pf_rows (= rows) of the grid
+    // (appended in round 5) K-sharded decode step: the rows as COMPLETE fp32 sums + weight_scale instead of fp16 u --
+    // u = fp16(fp16(z) * g) (bitnet.py:115-116) is formed here; u_gate / u_up are then not read
+    const float *z_gate, *z_up;      // [B, I]
+    const _Float16 *g_gate, *g_up;   // [I]
 };
 
 template <int NV>
@@ -189,8 +193,23 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
     for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         valid[v] = base < I;
-        g8[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + row + (valid[v] ? base : 0));
-        u8[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + row + (valid[v] ? base : 0));
+        if (A.z_gate) {                                          // (uniform) reduced sums of a K-sharded projection
+            const int b0 = valid[v] ? base : 0;
+            const ob_half8 gg = *reinterpret_cast<const ob_half8 *>(A.g_gate + b0), gu = *reinterpret_cast<const ob_half8 *>(A.g_up + b0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const ob_float4 zg = *reinterpret_cast<const ob_float4 *>(A.z_gate + row + b0 + 4 * q);
+                const ob_float4 zu = *reinterpret_cast<const ob_float4 *>(A.z_up + row + b0 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g8[v][4 * q + i] = (_Float16)(ob_round_h(zg[i]) * (float)gg[4 * q + i]);
+                    u8[v][4 * q + i] = (_Float16)(ob_round_h(zu[i]) * (float)gu[4 * q + i]);
+                }
+            }
+        } else {
+            g8[v] = *reinterpret_cast<const ob_half8 *>(A.u_gate + row + (valid[v] ? base : 0));
+            u8[v] = *reinterpret_cast<const ob_half8 *>(A.u_up + row + (valid[v] ? base : 0));
+        }
         if (A.h_next) hn[v] = *reinterpret_cast<const ob_half8 *>(A.h_next + (valid[v] ? base : 0));   // (used after the reduction)
     }
     float mg, rg, mu, ru;
@@ -198,7 +217,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_swiglu_kernel(const ObBSw
         const ob_float4 e = *reinterpret_cast<const ob_float4 *>(A.ext + (size_t)blockIdx.x * 4);
         mg = e[0]; rg = e[1]; mu = e[2]; ru = e[3];
     } else {
-        const float c0 = (float)A.u_gate[row], c1 = (float)A.u_up[row];
+        const float c0 = A.z_gate ? (float)(_Float16)(ob_round_h(A.z_gate[row]) * (float)A.g_gate[0]) : (float)A.u_gate[row];
+        const float c1 = A.z_gate ? (float)(_Float16)(ob_round_h(A.z_up[row]) * (float)A.g_up[0]) : (float)A.u_up[row];
         ob_float2 sg2 = {0.f, 0.f}, qg2 = {0.f, 0.f}, su2 = {0.f, 0.f}, qu2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < NV; ++v)

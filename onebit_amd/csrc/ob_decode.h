@@ -1194,7 +1194,22 @@ struct ObAttnArgs {
                                          // for a consumer that takes pre-scaled rows (batched step, ob_skinny3.h)
     const _Float16 *b_q, *b_k, *b_v;     // BIAS kernels (config.attention_bias, modeling_bitllama.py:451-453): q / k / v =
                                          // fp16(LayerNorm(u) + b) (bitnet.py:118-120) before the rotary embedding
+    // ZIN kernels (K-sharded decode step): the three rows as COMPLETE fp32 sums + weight_scale; u = fp16(fp16(z) * g)
+    // (bitnet.py:115-116) is formed on the fly and the statistics are recomputed per workgroup (u_q / u_k / u_v, st_* unused)
+    const float *z_q, *z_k, *z_v;
+    const _Float16 *g_q, *g_k, *g_v;
 };
+
+__device__ __forceinline__ _Float16 ob_zg(const float *z, const _Float16 *g, int i) { return (_Float16)(ob_round_h(z[i]) * (float)g[i]); }
+__device__ __forceinline__ ob_half8 ob_zg8(const float *z, const _Float16 *g, int base)
+{
+    const ob_float4 z0 = *reinterpret_cast<const ob_float4 *>(z + base), z1 = *reinterpret_cast<const ob_float4 *>(z + base + 4);
+    const ob_half8 gv = *reinterpret_cast<const ob_half8 *>(g + base);
+    ob_half8 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = (_Float16)(ob_round_h(z0[i]) * (float)gv[i]); u[4 + i] = (_Float16)(ob_round_h(z1[i]) * (float)gv[4 + i]); }
+    return u;
+}
 
 // Thread (pg, ds) = (tid >> 4, tid & 15): position group pg (32 of them, positions pg + 32 i) and
 // 8-dim slice ds of the head; a 16-lane DPP row spans the head dimension, so the q.k dots are row
@@ -1237,9 +1252,10 @@ __device__ __forceinline__ float ob_rows_max(float v)
 // PF (single sequence only): the launch runs one workgroup per head on a 256-CU chip -- the grid carries one extra
 // workgroup per idle CU that does nothing but pull o_proj's packed rows (the next launch: 2 MB) into the L2 of the XCD
 // whose workgroups will read them (ob_common.h).
-template <bool PST, int NTH, bool BLIND = true, bool BIAS = false>
+template <bool PST, int NTH, bool BLIND = true, bool BIAS = false, bool ZIN = false>
 __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in, const ObPfPlan PF)
 {
+    static_assert(!ZIN || !PST, "ZIN recomputes the statistics from the sums: non-PST form");
     ObAttnArgs A = A_in;
     if (BLIND) {
         // every kernel argument is requested in ONE scalar-load clause (hipcc fetches fields where they are first used:
@@ -1309,13 +1325,20 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             if (A.rope_cur) { rc0 = A.rope_cur[d0]; rs0 = A.rope_cur[D + d0]; rc1 = A.rope_cur[d1]; rs1 = A.rope_cur[D + d1]; }
         }
     }
-    const _Float16 cqh = PST ? (_Float16)0 : A.u_q[0], ckh = PST ? (_Float16)0 : A.u_k[0], cvh = PST ? (_Float16)0 : A.u_v[0];
+    const _Float16 cqh = PST ? (_Float16)0 : (ZIN ? ob_zg(A.z_q, A.g_q, 0) : A.u_q[0]), ckh = PST ? (_Float16)0 : (ZIN ? ob_zg(A.z_k, A.g_k, 0) : A.u_k[0]),
+                   cvh = PST ? (_Float16)0 : (ZIN ? ob_zg(A.z_v, A.g_v, 0) : A.u_v[0]);
     const int dq = min(tid, D - 1), dp = dq < half ? dq + half : dq - half;     // own and rotate_half partner
     _Float16 uqh = (_Float16)0, ukh = (_Float16)0, uvh = (_Float16)0, uqp = (_Float16)0, ukp = (_Float16)0;
     _Float16 bqh = (_Float16)0, bkh = (_Float16)0, bvh = (_Float16)0, bqp = (_Float16)0, bkp = (_Float16)0;
+    if (!PST && ZIN) {
+        uqh = ob_zg(A.z_q, A.g_q, head * D + dq); ukh = ob_zg(A.z_k, A.g_k, kvh * D + dq); uvh = ob_zg(A.z_v, A.g_v, kvh * D + dq);
+        uqp = ob_zg(A.z_q, A.g_q, head * D + dp); ukp = ob_zg(A.z_k, A.g_k, kvh * D + dp);
+    }
     if (!PST) {
-        uqh = A.u_q[head * D + dq]; ukh = A.u_k[kvh * D + dq]; uvh = A.u_v[kvh * D + dq];
-        uqp = A.u_q[head * D + dp]; ukp = A.u_k[kvh * D + dp];
+        if (!ZIN) {
+            uqh = A.u_q[head * D + dq]; ukh = A.u_k[kvh * D + dq]; uvh = A.u_v[kvh * D + dq];
+            uqp = A.u_q[head * D + dp]; ukp = A.u_k[kvh * D + dp];
+        }
         if (BIAS) {
             bqh = A.b_q[head * D + dq]; bkh = A.b_k[kvh * D + dq]; bvh = A.b_v[kvh * D + dq];
             bqp = A.b_q[head * D + dp]; bkp = A.b_k[kvh * D + dp];
@@ -1386,10 +1409,10 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         const float cq = (float)cqh, ck = (float)ckh, cv = (float)cvh;
         ob_float2 a2[6] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         for (int base = tid * 8; base < NQ; base += NTH * 8)
-            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
+            ob_stats8(ZIN ? ob_zg8(A.z_q, A.g_q, base) : *reinterpret_cast<const ob_half8 *>(A.u_q + base), cq, a2[0], a2[1]);
         for (int base = tid * 8; base < NK; base += NTH * 8) {
-            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
-            ob_stats8(*reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
+            ob_stats8(ZIN ? ob_zg8(A.z_k, A.g_k, base) : *reinterpret_cast<const ob_half8 *>(A.u_k + base), ck, a2[2], a2[3]);
+            ob_stats8(ZIN ? ob_zg8(A.z_v, A.g_v, base) : *reinterpret_cast<const ob_half8 *>(A.u_v + base), cv, a2[4], a2[5]);
         }
         float s[6];
 #pragma unroll

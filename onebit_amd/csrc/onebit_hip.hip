@@ -1759,24 +1759,22 @@ extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit
         return ob_launch_dec_gemv(a, s);
     }
     case ONEBIT_KSEG_ATTN_O: {
-        ObBZgArgs za = {};
-        za.s[0] = {st->z_qkv, (const _Float16 *)L.q.weight_scale, (_Float16 *)st->u_q, ts_q, NQ, 0};
-        za.s[1] = {st->z_qkv + NQ, (const _Float16 *)L.k.weight_scale, (_Float16 *)st->u_k, ts_k, NK, 0};
-        za.s[2] = {st->z_qkv + NQ + NK, (const _Float16 *)L.v.weight_scale, (_Float16 *)st->u_v, ts_v, NK, 0};
+        // the attention workgroups form u = fp16(fp16(z) * g) of the reduced q | k | v sums themselves and recompute the LayerNorm
+        // statistics from them (ZIN instances: 92 KB of L2 reads per head workgroup instead of one more launch per layer)
         if (!L.q.weight_scale || !L.k.weight_scale || !L.v.weight_scale) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
-        if ((rc = launch_zg(za, 3))) return rc;
         ObAttnArgs at = {};
         at.u_q = (const _Float16 *)st->u_q; at.u_k = (const _Float16 *)st->u_k; at.u_v = (const _Float16 *)st->u_v;
         at.cos = (const _Float16 *)m->rope_cos; at.sin = (const _Float16 *)m->rope_sin;
         at.kcache = (_Float16 *)L.k_cache; at.vcache = (_Float16 *)L.v_cache; at.out = (_Float16 *)st->attn_out;
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
-        at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
+        at.z_q = st->z_qkv; at.z_k = st->z_qkv + NQ; at.z_v = st->z_qkv + NQ + NK;
+        at.g_q = (const _Float16 *)L.q.weight_scale; at.g_k = (const _Float16 *)L.k.weight_scale; at.g_v = (const _Float16 *)L.v.weight_scale;
         at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
         const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: max_len %d too large for the attention kernel", m->max_len);
-        if (qkv_bias) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(m->n_heads), dim3(256), attn_lds, s, at, ObPfPlan{});
-        else hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(m->n_heads), dim3(256), attn_lds, s, at, ObPfPlan{});
+        if (qkv_bias) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, true, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
+        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, false, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
         if ((rc = ob_launch_status("decode_step_ksharded(attn)"))) return rc;
         a.nproj = 1; a.K = (int)L.o.K;
         if (st->k0_attn + L.o.K > NQ) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: o_proj slice of layer %d leaves the input vector", l);
@@ -1800,12 +1798,11 @@ extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit
         return ob_launch_dec_gemv(a, s);
     }
     default: {   // ONEBIT_KSEG_DOWN
-        ObBZgArgs za = {};
-        za.s[0] = {st->z_gu, (const _Float16 *)L.gate.weight_scale, (_Float16 *)st->u_gate, nullptr, I, 0};
-        za.s[1] = {st->z_gu + I, (const _Float16 *)L.up.weight_scale, (_Float16 *)st->u_up, nullptr, I, 0};
         if (!L.gate.weight_scale || !L.up.weight_scale) return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null weight_scale");
-        if ((rc = launch_zg(za, 2))) return rc;
-        ObBSwigluArgs sa = {(const _Float16 *)st->u_gate, (const _Float16 *)st->u_up, (_Float16 *)st->act, I, m->ln_eps, nullptr, nullptr};
+        ObBSwigluArgs sa = {};                 // the SwiGLU row kernel rounds and scales the reduced gate | up sums itself
+        sa.act = (_Float16 *)st->act; sa.I = I; sa.ln_eps = m->ln_eps;
+        sa.z_gate = st->z_gu; sa.z_up = st->z_gu + I;
+        sa.g_gate = (const _Float16 *)L.gate.weight_scale; sa.g_up = (const _Float16 *)L.up.weight_scale;
         OB_LAUNCH_SWIGLU(I, dim3(1), s, sa);
         if ((rc = ob_launch_status("decode_step_ksharded(swiglu)"))) return rc;
         a.nproj = 1; a.K = (int)L.down.K;

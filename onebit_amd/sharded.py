@@ -481,8 +481,9 @@ class StaticShapeDecoder:
 # all-reduce per BitLinearInf: 280 collectives and ~600 launches per 13B token; 101 tok/s at N = 1 against 620 for the fused
 # single-GPU engine).  Here the step is ``onebit_decode_step_ksharded`` (include/onebit.h): per layer four segments of
 # native kernels -- the decode GEMV in its fp32-partial form on the rank's K slice (q|k|v and gate|up as ONE launch and ONE
-# fp32 buffer each), one-workgroup row kernels for the replicated glue, the decode attention kernel -- and between them ONE
-# all-reduce of the named buffer: 4 collectives and 10 launches per layer, all of it under one HIP graph.
+# fp32 buffer each), one-workgroup row kernels for the replicated glue, the decode attention kernel (the consumers of a reduced sum
+# round and scale it themselves) -- and between them ONE all-reduce of the named buffer: 4 collectives and 8 launches per layer,
+# all of it under one HIP graph.
 #
 #   z_qkv [NQ + 2 NK] -> all_reduce -> z_o [H] -> all_reduce -> z_gu [2 I] -> all_reduce -> z_down [H] -> all_reduce
 #
