@@ -11,21 +11,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # worst max |logit - reference logit| over all routes, per golden array, as measured on MI355X (profiles/r05_model_parity.txt).
 # key: (fixture file, golden array name) -> (vs the reference's fp16 logits, vs its fp32 logits)
 OBSERVED = {
-    ("model_wide_d", "prefill_logits"): (0.02002, 0.01773),      # 32 layers, 7B widths: the reference's own fp16-fp32 gap is 0.01675
+    # maxima over 8 runs on different boxes (the module path's torch GEMMs -- eager attention, batched prefill -- are not bit-reproducible
+    # from box to box: a golden's worst error moves by up to 20 % between runs)
+    ("model_wide_d", "prefill_logits"): (0.02002, 0.01847),      # 32 layers, 7B widths: the reference's own fp16-fp32 gap is 0.01675
     ("model_wide_d", "decode_logits"): (0.01660, 0.01610),       #   (gap 0.01327)
     ("model_wide_d", "batch_prefill"): (0.01685, 0.01604),       #   (gap 0.01618)
-    ("model_wide_d", "batch_decode"): (0.01758, 0.01918),        #   (gap 0.01666)
+    ("model_wide_d", "batch_decode"): (0.02106, 0.01918),        #   (gap 0.01666)
     ("model_wide_c", "prefill_logits"): (0.00488, 0.00663),      # 2 layers, 7B widths (gap 0.00604)
     ("model_wide_c", "decode_logits"): (0.00488, 0.00676),       #   (gap 0.00632)
-    ("model_wide_c", "long_logits"): (0.00586, 0.00671),         #   4096-token prompt (gap 0.00601)
+    ("model_wide_c", "long_logits"): (0.00635, 0.00671),         #   4096-token prompt (gap 0.00601)
     ("model_wide_c", "batch_prefill"): (0.00490, 0.00742),       #   (gap 0.00669)
-    ("model_wide_c", "batch_decode"): (0.00586, 0.00755),        #   (gap 0.00779)
-    ("model_wide_e", "prefill_logits"): (0.00684, 0.00761),      # 2 layers, 13B widths (gap 0.00761)
-    ("model_wide_e", "decode_logits"): (0.00781, 0.00745),       #   (gap 0.00600)
+    ("model_wide_c", "batch_decode"): (0.00586, 0.00767),        #   (gap 0.00779)
+    ("model_wide_c", "kshard_decode"): (0.00488, 0.00625),       #   FusedKShardedDecoder, worlds 3 / 8 in lockstep on one device
+    ("model_wide_e", "prefill_logits"): (0.00774, 0.00761),      # 2 layers, 13B widths (gap 0.00761)
+    ("model_wide_e", "decode_logits"): (0.00781, 0.00762),       #   (gap 0.00600)
     ("model_wide_e", "batch_prefill"): (0.00586, 0.00766),       #   (gap 0.00651)
     ("model_wide_e", "batch_decode"): (0.00586, 0.00747),        #   (gap 0.00764)
-    ("model_wide_e", "kshard_decode"): (0.00684, 0.00680),       # FusedKShardedDecoder, worlds 1 / 2 / 4 / 8 in lockstep on one device
-    ("model_wide_c", "kshard_decode"): (0.00488, 0.00673),       #   worlds 3 / 8
+    ("model_wide_e", "kshard_decode"): (0.00781, 0.00769),       #   FusedKShardedDecoder, worlds 1 / 2 / 4 / 8
 }
 
 
