@@ -76,6 +76,17 @@ def test_argument_errors_without_gpu():
     lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), ctypes.c_void_p]
     assert lib.onebit_decode_step(ctypes.byref(m), ctypes.byref(ds), None) == E_ARG                # struct_size 0
     assert b"struct_size" in lib.onebit_last_error()
+    # the K-sharded decode step validates before any launch as well: null / foreign-size state, unknown segment, layer range
+    from onebit_amd.engine import _KState
+    lib.onebit_decode_step_ksharded.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_KState), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    assert lib.onebit_decode_step_ksharded(None, None, 0, 0, None) == E_ARG
+    ks = _KState()
+    assert lib.onebit_decode_step_ksharded(ctypes.byref(m), ctypes.byref(ks), 0, 0, None) == E_ARG and b"struct_size" in lib.onebit_last_error()
+    ks.struct_size = ctypes.sizeof(_KState)
+    m16 = _Model(1, 64, 128, 2, 2, 32, 16, 8, 1e-6, 1e-5, layers, a, a, a, a, a)
+    assert lib.onebit_decode_step_ksharded(ctypes.byref(m16), ctypes.byref(ks), 0, 9, None) == E_FLAG      # unknown segment
+    assert lib.onebit_decode_step_ksharded(ctypes.byref(m16), ctypes.byref(ks), 5, 0, None) == E_ARG       # layer outside the model
+    assert lib.onebit_decode_step_ksharded(ctypes.byref(m16), ctypes.byref(ks), 0, 0, None) == E_ARG       # null buffers
     with pytest.raises(ValueError):
         _lib.check(E_SHAPE, "x")
     with pytest.raises(RuntimeError):
