@@ -187,3 +187,50 @@ def test_fused_k_sharded_decoder_world1_equals_engine_tokens(golden_dir, use_gra
     rc = dec.backend.lib.onebit_decode_step_ksharded(ctypes.byref(dec.backend._model), ctypes.byref(st), 0, 0, None)
     assert rc != 0 and b"128" in dec.backend.lib.onebit_last_error()
     st.k0_hidden = 0
+
+
+@pytest.mark.parametrize("name,cfgkw,world", [
+    ("gqa", dict(vocab_size=640, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=8,
+                 num_key_value_heads=2, max_position_embeddings=64), 2),
+    ("gqa", dict(vocab_size=640, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=8,
+                 num_key_value_heads=2, max_position_embeddings=64), 4),
+    ("bias", dict(vocab_size=512, hidden_size=512, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=4,
+                  max_position_embeddings=64, attention_bias=True), 2),
+])
+def test_fused_k_sharded_decoder_gqa_and_bias_vs_engine(name, cfgkw, world):
+    """Grouped-query attention (n_kv_heads < n_heads: the q | k | v exchange buffer is [NQ + 2 NK] with NK != NQ, the ZIN attention
+    indexes kv heads) and attention_bias (q / k / v bias in the ZIN attention, o bias in the row kernel that consumes z_o) through
+    the K-sharded segments, `world` ranks in lockstep on one device, against the single-GPU engine on the same checkpoint:
+    teacher-forced logits within the fp16 noise of two summation orders, the same greedy token wherever the margin is clear."""
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.sharded import FusedKShardedDecoder, lockstep_step
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(**cfgkw)
+    model = build_synthetic_model(cfg, seed=31, device=dev)
+    if name == "bias":
+        assert model.model.layers[0].self_attn.o_proj.bias is not None
+    ids = torch.randint(0, cfg.vocab_size, (1, 7), generator=torch.Generator().manual_seed(3)).to(dev)
+    eng = DecodeEngine(model, max_len=32)
+    eng.prefill(ids)
+    decs = [FusedKShardedDecoder(model, r, world, max_len=32, use_graph=False, reduce_fn=lambda t: None) for r in range(world)]
+    for d in decs:
+        assert d.prime(ids) == eng.first_token
+    tok = eng.first_token
+    for i in range(6):
+        eng.set_state(tok, ids.shape[1] + i)
+        eng.step()
+        ref = eng.logits().cpu().numpy()
+        for d in decs:
+            d.set_state(tok, ids.shape[1] + i)
+        lockstep_step(decs)
+        torch.cuda.synchronize()
+        got = decs[0].logits().cpu().numpy()
+        scale = float(np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 6e-3 * scale, (name, world, i, float(np.abs(got - ref).max()), scale)
+        srt = np.sort(ref)
+        if srt[-1] - srt[-2] > 1.2e-2 * scale:
+            assert int(got.argmax()) == int(ref.argmax())
+        for d in decs[1:]:
+            assert torch.equal(d.buf["logits"], decs[0].buf["logits"])
+        tok = int(ref.argmax())
