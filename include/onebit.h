@@ -266,6 +266,11 @@ typedef struct onebit_decode_state {
      * cos[pos], sin[pos] there and the 32 attention launches read THAT instead of chasing pos -> cos / sin
      * themselves (one dependent memory round trip less on every layer's critical path).  NULL: as before.    */
     void *rope_cur;
+    /* ABI 8, optional: 64 = the single-launch attention requests only the first 64 cached positions before it knows the
+     * position (32 KB per head instead of 64 KB: the launch is bound by that fetch) and streams the rest once it does.  A
+     * PERFORMANCE hint for steps the host knows to be at a position < 64 -- results do not depend on it at any position.
+     * 0 / 128: the 128-position window.                                                                              */
+    int32_t attn_blind;
 } onebit_decode_state_t;
 
 size_t onebit_attn_scratch_bytes(const onebit_model_t *model, int32_t splits);

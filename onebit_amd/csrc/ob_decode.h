@@ -1252,10 +1252,14 @@ __device__ __forceinline__ float ob_rows_max(float v)
 // PF (single sequence only): the launch runs one workgroup per head on a 256-CU chip -- the grid carries one extra
 // workgroup per idle CU that does nothing but pull o_proj's packed rows (the next launch: 2 MB) into the L2 of the XCD
 // whose workgroups will read them (ob_common.h).
-template <bool PST, int NTH, bool BLIND = true, bool BIAS = false, bool ZIN = false>
+// NB (round 5): positions whose K / V rows are requested before the position is known and whose scores stay in registers (the
+// "blind window").  128 reads 64 KB per head workgroup whatever the context holds; a step the HOST knows to be at a position
+// < 64 takes the NB = 64 instance (half the rows: the launch is bound by that fetch, not by its arithmetic).
+template <bool PST, int NTH, bool BLIND = true, bool BIAS = false, bool ZIN = false, int NB = 128>
 __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in, const ObPfPlan PF)
 {
     static_assert(!ZIN || !PST, "ZIN recomputes the statistics from the sums: non-PST form");
+    static_assert(NB == 128 || NB == 64, "blind window");
     ObAttnArgs A = A_in;
     if (BLIND) {
         // every kernel argument is requested in ONE scalar-load clause (hipcc fetches fields where they are first used:
@@ -1265,7 +1269,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
                      "s"(A.D), "s"(A.max_len), "s"(A.ln_eps));
     }
     if (BLIND && ob_prefetch_only_wg(PF, A_in.H, (int)threadIdx.x, NTH)) return;
-    constexpr int NWV = NTH / 64, PG = NTH / 16, NI = 128 / PG;
+    constexpr int NWV = NTH / 64, PG = NTH / 16, NI = NB / PG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = A.D, H = A.H, Hkv = A.Hkv;
     const int head = blockIdx.x, kvh = head / (H / Hkv);
@@ -1478,7 +1482,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             lmax = fmaxf(lmax, sreg[i]);
         }
     }
-    for (int p0 = 128; p0 < L; p0 += 128) {
+    for (int p0 = NB; p0 < L; p0 += NB) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int p = p0 + pg + PG * i;
@@ -1510,7 +1514,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
         if (BLIND || PG * i < L) { sreg[i] = __expf(sreg[i] - gmax); lsum += sreg[i]; }      // exp(-inf) = 0
         else sreg[i] = 0.f;
     }
-    for (int p0 = 128; p0 < L; p0 += 128) {
+    for (int p0 = NB; p0 < L; p0 += NB) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int p = p0 + pg + PG * i;
@@ -1548,7 +1552,7 @@ __global__ __launch_bounds__(NTH) void ob_dec_attn_kernel(const ObAttnArgs A_in,
             }
         }
     }
-    for (int p0 = 128; p0 < L; p0 += 128) {
+    for (int p0 = NB; p0 < L; p0 += NB) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int p = p0 + pg + PG * i;

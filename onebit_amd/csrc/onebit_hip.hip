@@ -1598,14 +1598,20 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
             // leave idle: 986-989 -> 1004 tok/s on one box, alternating runs.  (The same for gate|up's 11 MB, or from the
             // GEMV launches' tails, loses: DESIGN.md section 6.)
             static const int attn_pf_env = getenv("OB_DEC_PREFETCH_O") ? atoi(getenv("OB_DEC_PREFETCH_O")) : 1;
+            static const int blind_env = getenv("OB_ATTN_BLIND") ? atoi(getenv("OB_ATTN_BLIND")) : 0;      // A/B override: 64 / 128
+            const bool blind64 = (blind_env ? blind_env : st->attn_blind) == 64;
             ObPfPlan apf = {};
             if (attn_pf_env && m->n_heads < ob_cu_count()) apf = ob_dec_gemv_plan(o);
             const int agrid = apf.nseg ? ob_cu_count() : m->n_heads;
+            if (st->attn_blind != 0 && st->attn_blind != 64 && st->attn_blind != 128)
+                return ob_fail(ONEBIT_E_FLAG, "decode_step: attn_blind %d (0, 64 or 128)", st->attn_blind);
             if (qkv_bias) {         // config.attention_bias: the BIAS instances (q / k / v = fp16(LayerNorm(u) + b) before RoPE)
-                if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
+                if (at.st_q && attn_threads == 256 && blind64) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true, false, 64>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
+                else if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
                 else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512, true, true>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
                 else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, true>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
             }
+            else if (at.st_q && attn_threads == 256 && blind64) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, false, false, 64>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
             else if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
             else if (at.st_q) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);
             else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512>), dim3(agrid), dim3(512), attn_lds, s, at, apf);

@@ -50,7 +50,7 @@ class _State(ctypes.Structure):
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp),
-                ("tile_stats", _vp), ("rope_cur", _vp)]
+                ("tile_stats", _vp), ("rope_cur", _vp), ("attn_blind", _i32)]
 
 
 class _BatchState(ctypes.Structure):
@@ -216,7 +216,7 @@ class DecodeEngine:
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
-                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None, None)
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None, None, 0)
         self._rope_cur = z(2 * D)
         self._state.rope_cur = self._rope_cur.data_ptr()
         self.lib.onebit_decode_stats_floats.restype = ctypes.c_size_t
@@ -226,7 +226,7 @@ class DecodeEngine:
         self._state.tile_stats = self._tile_stats.data_ptr()
         self.lib.onebit_decode_step.restype = ctypes.c_int
         self.lib.onebit_decode_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_State), _vp]
-        self.graph = self.graph_long = None
+        self.graph = self.graph_long = self.graph64 = None
         self._prompt_len = 0
         self._steps = 0                     # host-side count of tokens in the cache (chooses the graph)
         self._long_from = int(long_context_from) if long_context_from and self.max_len > long_context_from else 0
@@ -237,14 +237,22 @@ class DecodeEngine:
             if not long_context_from:
                 raise ValueError(f"max_len {self.max_len} needs the split-KV attention (long_context_from > 0)")
             self._long_from = 1
+        # steps at positions < 64: the attention requests half the rows before it knows the position (onebit.h, attn_blind);
+        # the same arithmetic, chosen per step by the host-known position like the split-KV graph below
+        self._state64 = _State.from_buffer_copy(self._state)
+        self._state64.attn_blind = 64
         if self._short_ok:
-            self._launch()                  # warm-up: validates arguments, sets function attributes
-            torch.cuda.synchronize(dev)
-            if use_graph:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._launch()
-                self.graph = g
+            for st64 in (False, True):
+                self._launch(blind64=st64)  # warm-up: validates arguments, sets function attributes
+                torch.cuda.synchronize(dev)
+                if use_graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._launch(blind64=st64)
+                    if st64:
+                        self.graph64 = g
+                    else:
+                        self.graph = g
         if self._long_from:
             S = max(2, min(int(attn_splits), 16, self.max_len // 128))
             self.lib.onebit_attn_scratch_bytes.restype = ctypes.c_size_t
@@ -265,9 +273,10 @@ class DecodeEngine:
         self.pos.zero_()
         self.token.zero_()
 
-    def _launch(self, long: bool = False):
+    def _launch(self, long: bool = False, blind64: bool = False):
+        st = self._state_long if long else (self._state64 if blind64 else self._state)
         with torch.cuda.device(self.dev):
-            rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(self._state_long if long else self._state),
+            rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(st),
                                              torch.cuda.current_stream(self.dev).cuda_stream)
         _lib.check(rc, "onebit_decode_step")
 
@@ -306,11 +315,12 @@ class DecodeEngine:
         if self._steps >= self.max_len:
             raise RuntimeError(f"DecodeEngine.step: KV cache full ({self.max_len} positions); build the engine with a larger max_len")
         long = bool(self._long_from) and (self._steps >= self._long_from or not self._short_ok)
-        g = self.graph_long if long else self.graph
+        b64 = not long and self._steps < 64
+        g = self.graph_long if long else (self.graph64 if b64 else self.graph)
         if g is not None:
             g.replay()
         else:
-            self._launch(long=long)
+            self._launch(long=long, blind64=b64)
         self._steps += 1
 
     def logits(self) -> torch.Tensor:

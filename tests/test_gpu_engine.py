@@ -191,6 +191,10 @@ def test_fused_gemv_each_prologue(H, I):
     # the same through the split-KV attention (4 splits of 128 positions: 3 hold data at 300 tokens)
     (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
           max_position_embeddings=512), 300, 6, dict(long_context_from=64, attn_splits=4)),
+    # positions 55 .. 74: the first nine steps replay the graph whose attention requests 64 positions before it knows the
+    # position (onebit_decode_state_t.attn_blind), the rest the 128-position graph -- the same logits on either side of 64
+    (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+          max_position_embeddings=128), 55, 20, dict(long_context_from=0)),
     # split-KV with grouped-query attention and a position crossing a split boundary (chunk = 32)
     (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
           num_key_value_heads=2, max_position_embeddings=256), 60, 10, dict(long_context_from=16, attn_splits=8)),
@@ -214,6 +218,7 @@ def test_engine_attention_variants(cfgkw, prompt_len, steps, engine_kw):
         ref_toks.append(int(tok))
     eng = DecodeEngine(model, max_len=cfg.max_position_embeddings, **engine_kw)
     assert (eng.graph_long is not None) == bool(engine_kw.get("long_context_from"))
+    assert eng.graph64 is not None and eng._state64.attn_blind == 64 and eng._state.attn_blind == 0
     eng.prefill(ids)
     assert eng.first_token == ref_toks[0]
     ref = np.stack(ref_logits)
@@ -448,3 +453,33 @@ def test_one_projection_per_workgroup_launches(coracle, K, Ns, use_stats):
             pub = st.cpu().numpy()[: 2 * (N // 16)].reshape(-1, 2)
             np.testing.assert_allclose(pub[:, 0], s, rtol=1e-5, atol=1e-4)
             np.testing.assert_allclose(pub[:, 1], m2, rtol=1e-4, atol=1e-4)
+
+
+def test_attn_blind_hint_does_not_change_results():
+    """onebit_decode_state_t.attn_blind = 64 is a performance hint: the attention launch requests 64 instead of 128 cached
+    positions before it knows the position and streams the rest -- logits bit-identical to the 128-position window at
+    positions below, at and far above 64 (direct launches, no graph), and an unknown value is refused."""
+    import ctypes
+    from onebit_amd import _lib
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                            max_position_embeddings=256)
+    model = build_synthetic_model(cfg, seed=12, device=dev)
+    ids = torch.randint(0, cfg.vocab_size, (1, 200), generator=torch.Generator().manual_seed(5)).to(dev)
+    eng = DecodeEngine(model, max_len=256, use_graph=False, long_context_from=0)
+    eng.prefill(ids)                                           # the cache holds 200 positions
+    for pos in (5, 63, 64, 65, 130, 199):
+        outs = []
+        for b64 in (False, True):
+            eng.set_state(7, pos)
+            eng._launch(blind64=b64)
+            torch.cuda.synchronize()
+            outs.append(eng.buf["logits"].clone())
+        assert torch.equal(outs[0], outs[1]), pos
+    eng._state64.attn_blind = 32
+    eng.set_state(7, 5)
+    with pytest.raises(Exception, match="attn_blind"):
+        eng._launch(blind64=True)
+    eng._state64.attn_blind = 64
