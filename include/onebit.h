@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ONEBIT_ABI_VERSION 8
+#define ONEBIT_ABI_VERSION 9
 
 #define ONEBIT_F16 0
 #define ONEBIT_F32 1
@@ -375,6 +375,78 @@ typedef struct onebit_kshard_state {
 } onebit_kshard_state_t;
 int onebit_decode_step_ksharded(const onebit_model_t *model, const onebit_kshard_state_t *state, int32_t layer,
                                 int32_t segment, void *stream);
+
+/* ---- ragged token rows: several sequences in one call (continuous batching, BASELINE config 5; ABI 9) -----------------
+ * The reference runs one rectangular batch per forward (modeling_bitllama.py:1275-1330); a continuous-batching step instead
+ * concatenates the token rows of all scheduled requests: item i = rows [row0, row0 + n) of the request whose KV cache is slot
+ * `slot`, its first new token at position `past` (keys 0 .. past + n - 1 of that slot are valid once the rows' keys / values
+ * have been appended).  The arithmetic per row is the reference's (attention with past: :487-585). */
+typedef struct onebit_seg { int32_t row0, n, slot, past; } onebit_seg_t;
+
+/* onebit_rows_qkv_rope for ragged rows: LayerNorm of the three pre-LayerNorm rows (bitnet.py:118), RoPE at the row's OWN position
+ * (modeling_bitllama.py:175-181), k / v appended to cache row [row_slot[t]][kv head][row_pos[t]], q token-major [T, n_heads, D].
+ * row_slot (NULL: slot = t) / row_pos: DEVICE int32 [T]; a row whose slot / position lies outside [0, n_slots) x [0, max_len)
+ * is skipped (an idle decode slot).  caches [n_slots][n_kv_heads][max_len][head_dim]; cos / sin [max_pos >= max_len, head_dim]. */
+int onebit_rows_qkv_rope_ragged(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                                const int32_t *row_slot, const int32_t *row_pos, void *q, void *k_cache, void *v_cache,
+                                int64_t T, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots,
+                                int64_t max_len, int64_t max_pos, float ln_eps, void *stream);
+
+/* onebit_attention_prefill over ragged segments: causal attention of every segment's n queries (rows row0 .. of q, token-major
+ * [rows, n_heads, D]) against keys 0 .. past + n - 1 of its slot; o [rows, n_heads, D] (x h_next when given).  `segs` is a HOST
+ * array (it travels in the kernel arguments, 64 segments per launch: nothing to upload, graph-capture safe).  head_dim 64 / 128. */
+int onebit_attention_ragged(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next_or_null,
+                            const onebit_seg_t *segs, int32_t n_seg, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                            int64_t n_slots, int64_t max_len, void *stream);
+
+/* Decode attention for single-token rows at ANY context length (modeling_bitllama.py:546-563 with q_len = 1): row r attends to keys
+ * 0 .. row_pos[r] of slot row_slot[r] (NULL: slot r; the row's own key / value already appended: onebit_rows_qkv_rope_ragged), the
+ * positions split over `n_splits` workgroups of `chunk` positions each per (row, head) (flash-decoding; chunk a multiple of 64,
+ * chunk * n_splits >= the longest context + 1 -- positions beyond that are NOT attended), partial results combined by the last
+ * workgroup to arrive, in split order (deterministic).  q [rows, n_heads, D] post-RoPE, o [rows, n_heads * D] (x h_next).
+ * scratch: onebit_attention_decode_scratch_bytes(rows, n_heads, n_splits) bytes, ZERO-FILLED ONCE by the caller (the arrival tickets
+ * -- the first rows * n_heads int32 of it, whatever n_splits is -- return to zero after every launch; a scratch that is reused with
+ * another `rows` or `n_heads` must be zero-filled again); n_splits == 1 needs none.  Scores are rounded as the reference's eager attention rounds them;
+ * probabilities are not rounded to fp16 before the value product (as in onebit_attention_prefill). */
+size_t onebit_attention_decode_scratch_bytes(int64_t rows, int32_t n_heads, int32_t n_splits);
+int onebit_attention_decode_rows(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next_or_null,
+                                 const int32_t *row_slot, const int32_t *row_pos, int64_t rows, int32_t n_heads, int32_t n_kv_heads,
+                                 int32_t head_dim, int64_t n_slots, int64_t max_len, int32_t chunk, int32_t n_splits, void *scratch,
+                                 size_t scratch_bytes, void *stream);
+
+/* ---- mixed prefill + decode step (BASELINE config 5: "mixed prefill+decode continuous batch") ---------------------------
+ * ONE scheduler step on native kernels: the token rows of all scheduled items -- first the single next token of every decoding
+ * request (n_dec rows), then the prompt chunks of the requests still entering (n_seg segments) -- go through every 1-bit
+ * projection as ONE GEMM over all n_rows rows (packed weights streamed once per step), the row glue runs fused
+ * (residual + LayerNorm + RMSNorm writing the consumers' pre-scaled rows; LayerNorm + RoPE + cache append per row at its own
+ * (slot, position); SiLU(LayerNorm) * LayerNorm), attention runs per item on its own cache slot (prompt chunks: causal flash
+ * attention with past on MFMA; decode rows: split-KV), and the lm_head + greedy token run on the n_out rows that sample.
+ * 9-13 launches per decoder layer whatever the number of items; no per-item loop on the host.
+ * model->layers[l].k_cache / v_cache: [n_slots][n_kv_heads][max_len][head_dim].  No q / k / v biases (o bias is taken).  */
+typedef struct onebit_mixed_state {
+    uint64_t struct_size;        /* sizeof(onebit_mixed_state_t) as the caller compiled it (checked)                          */
+    int32_t n_rows;              /* token rows of the step                                                                    */
+    int32_t n_dec;               /* rows 0 .. n_dec - 1: one token each of n_dec different requests                           */
+    int32_t n_seg;               /* prompt chunks; their rows tile [n_dec, n_rows) in order                                   */
+    int32_t n_out;               /* rows whose greedy next token is wanted                                                    */
+    int32_t n_slots;             /* slots of the KV caches                                                                    */
+    int32_t attn_chunk;          /* positions per split of the decode rows' attention (0: 256)                                */
+    int32_t dec_ctx;             /* host-known bound on row_pos + 1 over the decode rows (sizes the split grid); 0: max_len   */
+    const int32_t *tokens;       /* device [n_rows] token ids                                                                 */
+    const int32_t *row_slot;     /* device [n_rows] cache slot of every row                                                   */
+    const int32_t *row_pos;      /* device [n_rows] position of every row's token                                             */
+    const onebit_seg_t *segs;    /* HOST [n_seg]                                                                              */
+    const int32_t *out_rows;     /* device [n_out]: the rows that sample (last row of an item whose prompt is complete)       */
+    int32_t *next_tokens;        /* device [n_out] out                                                                        */
+    void *logits;                /* optional fp16 [n_out, vocab]                                                              */
+    float *part_val;             /* fp32 [ceil(vocab / 128) * 64] scratch                                                     */
+    int32_t *part_idx;           /* int32 [ceil(vocab / 128) * 64] scratch                                                    */
+    void *workspace;             /* onebit_mixed_workspace_bytes(...) bytes, 256-byte aligned, ZERO-FILLED ONCE               */
+    size_t workspace_bytes;
+} onebit_mixed_state_t;
+/* max_dec_rows = state->n_slots of the steps that will use the workspace (the attention scratch is laid out for that many rows). */
+size_t onebit_mixed_workspace_bytes(const onebit_model_t *model, int64_t max_rows, int32_t max_dec_rows, int32_t attn_chunk);
+int onebit_mixed_step(const onebit_model_t *model, const onebit_mixed_state_t *state, void *stream);
 
 /* One fused decode GEMV launch (the building block of onebit_decode_step, exposed so that a
  * single kernel can be measured and tested in isolation): up to 3 projections sharing the input

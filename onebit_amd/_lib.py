@@ -19,7 +19,7 @@ FLAG_SKIP_LN = 1
 FLAG_Q_TOKEN_MAJOR = 2      # onebit_rows_qkv_rope
 FLAG_PRESCALED = 4
 FLAG_TILE_STATS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); must list every symbol include/onebit.h declares
 _i64, _vp, _int, _f, _u = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
@@ -46,6 +46,13 @@ SYMBOLS = {
     "onebit_rows_qkv_rope_stats": (_int, [_vp] * 9 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_attention_prefill": (_int, [_vp] * 5 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _vp]),
+    "onebit_rows_qkv_rope_ragged": (_int, [_vp] * 10 + [_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, _vp]),
+    "onebit_attention_ragged": (_int, [_vp] * 6 + [ctypes.c_int32] * 4 + [_i64, _i64, _vp]),
+    "onebit_attention_decode_scratch_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, ctypes.c_int32]),
+    "onebit_attention_decode_rows": (_int, [_vp] * 7 + [_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, ctypes.c_int32, ctypes.c_int32,
+                                                      _vp, ctypes.c_size_t, _vp]),
+    "onebit_mixed_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, ctypes.c_int32, ctypes.c_int32]),
+    "onebit_mixed_step": (_int, [_vp, _vp, _vp]),     # (onebit_model_t*, onebit_mixed_state_t*, stream)
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),
     "onebit_decode_stats_floats": (ctypes.c_size_t, [_vp]),
     "onebit_batch_stats_floats": (ctypes.c_size_t, [_vp, ctypes.c_int32]),

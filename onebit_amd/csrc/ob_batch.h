@@ -31,6 +31,8 @@ struct ObBNormArgs {
     // (appended in round 5: the fields above keep their kernarg offsets)
     const _Float16 *bias_prev;    // optional [H]: bias of the projection that produced u_prev (o_proj with config.attention_bias):
                                   //   r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120, then :912)
+    // (appended in round 6) optional [grid]: workgroup t READS row rows[t] of hres_in / u_prev and writes row t of the outputs --
+    const int *rows;              //   the final norm of a mixed step on the rows whose logits are wanted (onebit_mixed_step)
 };
 
 // NV = 8-half vectors per thread actually populated: ceil(H / 4096).  (Sized OB_DEC_MAXV = 4 for every width, a 4096-wide
@@ -41,8 +43,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, H = A.H;
     if (ob_prefetch_only_wg(A.pf, A.pf_rows, tid, OB_DEC_THREADS)) return;
-    const int64_t row = (int64_t)blockIdx.x * H;
-    const _Float16 *src = EMBED ? A.embed + (int64_t)A.tokens[blockIdx.x] * H : A.hres_in + row;
+    const int64_t row = (int64_t)blockIdx.x * H;                       // row written
+    const int64_t rin = (!EMBED && A.rows) ? (int64_t)A.rows[blockIdx.x] * H : row;       // row read (uniform pointer test)
+    const _Float16 *src = EMBED ? A.embed + (int64_t)A.tokens[blockIdx.x] * H : A.hres_in + rin;
     ob_half8 hv[NV], uv[NV];
     // the vectors of the LAST phase (RMSNorm weight, the consumers' input_factor) are requested here, with the rows: asked
     // for after the two block reductions, their L2 round trip was the tail of every launch
@@ -60,14 +63,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
         if (!EMBED) {
             const int b0 = valid[v] ? base : 0;
             if (A.u_prev) {
-                uv[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + row + b0);
+                uv[v] = *reinterpret_cast<const ob_half8 *>(A.u_prev + rin + b0);
             } else {                                // split-K partials: the epilogue of bitnet.py:115-116 happens here
                 const ob_half8 gv = *reinterpret_cast<const ob_half8 *>(A.g_prev + b0);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z0 + row + b0 + 4 * q);
+                    const ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z0 + rin + b0 + 4 * q);
                     // (z1 == NULL: one complete sum, the all-reduced partials of a K-sharded projection -- uniform test)
-                    const ob_float4 b = A.z1 ? *reinterpret_cast<const ob_float4 *>(A.z1 + row + b0 + 4 * q) : (ob_float4){0.f, 0.f, 0.f, 0.f};
+                    const ob_float4 b = A.z1 ? *reinterpret_cast<const ob_float4 *>(A.z1 + rin + b0 + 4 * q) : (ob_float4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         uv[v][4 * q + i] = (_Float16)(ob_round_h(a[i] + b[i]) * (float)gv[4 * q + i]);
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     }
     if (!EMBED) {
         // pivot of the shifted sums = element 0 of the row, the same value in every thread
-        const float c0 = A.u_prev ? (float)A.u_prev[row]
-                                  : (float)(_Float16)(ob_round_h(A.z0[row] + (A.z1 ? A.z1[row] : 0.f)) * (float)A.g_prev[0]);
+        const float c0 = A.u_prev ? (float)A.u_prev[rin]
+                                  : (float)(_Float16)(ob_round_h(A.z0[rin] + (A.z1 ? A.z1[rin] : 0.f)) * (float)A.g_prev[0]);
         ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < NV; ++v)
@@ -267,6 +270,11 @@ struct ObQkvRopeArgs {
     float ln_eps;
     const float *ext;                    // optional [T, 6] {mean, rstd} of the COMPLETE q, k, v rows (tensor-parallel: the rows
                                          // given here hold the rank's heads only)
+    // (round 6) RAGGED rows -- the token rows of several sequences in one launch (mixed prefill + decode step, long-context
+    // decode steps): row t belongs to cache slot row_slot[t] (NULL: slot t) and sits at position row_pos[t]; q stays
+    // token-major.  A row whose slot / position lies outside [0, n_slots) x [0, max_len) is skipped (idle decode slot).
+    const int *row_slot, *row_pos;       // device [T]; row_pos != NULL selects this form (S, past unused)
+    int n_slots;
 };
 
 template <int NV>
@@ -275,7 +283,14 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
     __shared__ __attribute__((aligned(16))) float red[128];
     const int tid = threadIdx.x, D = A.D, half = D >> 1;
     const int NQ = A.H * D, NK = A.Hkv * D;
-    const int t = blockIdx.x, b = t / A.S, sp = t - b * A.S, pos = A.past + sp;
+    const int t = blockIdx.x;
+    int b, sp, pos;
+    if (A.row_pos) {                                        // ragged rows (uniform pointer test)
+        b = A.row_slot ? A.row_slot[t] : t; pos = A.row_pos[t]; sp = 0;
+        if (b < 0 || b >= A.n_slots || pos < 0 || pos >= A.max_len) return;      // idle row: the whole workgroup leaves
+    } else {
+        b = t / A.S; sp = t - b * A.S; pos = A.past + sp;
+    }
     const _Float16 *uq = A.u_q + (int64_t)t * NQ, *uk = A.u_k + (int64_t)t * NK, *uv = A.u_v + (int64_t)t * NK;
     // thread owns 8 consecutive elements of each vector per pass (D % 8 == 0: never straddles a head), and
     // fetches their rotate_half partners (same head, d +- D/2) alongside
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
                 const float xr = d0 < half ? -x1 : x1;
                 o[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
             }
-            _Float16 *qd = A.q_bshd ? A.q + (int64_t)t * NQ + base : A.q + (((int64_t)b * A.H + hd) * A.S + sp) * D + d0;
+            _Float16 *qd = (A.q_bshd || A.row_pos) ? A.q + (int64_t)t * NQ + base : A.q + (((int64_t)b * A.H + hd) * A.S + sp) * D + d0;
             *reinterpret_cast<ob_half8 *>(qd) = o;
         }
         if (vk[v]) {

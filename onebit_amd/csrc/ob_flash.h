@@ -59,6 +59,20 @@ struct ObFlashArgs {
 #endif
 };
 
+// RAGGED form (round 6, the mixed prefill + decode step of continuous batching): the queries are the token rows of SEVERAL
+// sequences, concatenated; segment i = rows [row0, row0 + n) of the request in KV-cache slot `slot`, first new token at position
+// `past` (its keys 0 .. past + n - 1 are in the cache).  The segment table travels in the kernel arguments (<= 64 segments per
+// launch: no device-side table to upload, graph-capture safe); wg_end[i] = workgroups of segments 0 .. i (n_heads * ceil(query
+// blocks / 2) each).  Everything else is the kernel above with (b, S, past) read per segment.
+#define OB_FL_MAXSEG 64
+struct ObFlashSeg { int row0, n, slot, past; };
+struct ObFlashRaggedArgs {
+    ObFlashArgs a;            // q / o [rows, H, D]; k / v [slots][Hkv][max_len][D]; S, past, nmb unused
+    int nseg;
+    int wg_end[OB_FL_MAXSEG];
+    ObFlashSeg seg[OB_FL_MAXSEG];
+};
+
 #define OB_FL_BM 128
 #define OB_FL_BN 64
 #define OB_FL_THREADS 256
@@ -92,9 +106,10 @@ __device__ __forceinline__ float ob_fl_col_sum(float v)
 #define OB_FL_DEFER_THR 8.0f    // log2 units: the running maximum is kept while the new tile's maximum exceeds it by less (P <= 2^8)
 #endif
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs A)
+template <int D, bool RAGGED = false>
+__global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const std::conditional_t<RAGGED, ObFlashRaggedArgs, ObFlashArgs> AA)
 {
+    const ObFlashArgs &A = [&]() -> const ObFlashArgs & { if constexpr (RAGGED) return AA.a; else return AA; }();
     constexpr int DT = D / 16, DK = D / 32;
     constexpr int NPC = D / 8;                  // 16-byte pieces per K / V row
     constexpr int KLD = OB_FL_BN * NPC / 256;   // K (and V) pieces per thread and block (4 at D = 128)
@@ -120,12 +135,29 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
     const int bid = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
     // Causal balance: a workgroup takes query block npair - 1 - j .. and then block j of its (sequence, head) -- every
     // workgroup sweeps the same number of key blocks (heaviest-first dealing of single blocks left a 12 % tail)
-    const int npair = (A.nmb + 1) >> 1;
-    const int pj = bid % npair;
-    const int bh = bid / npair;
-    const int head = bh % A.H, b = bh / A.H;
+    int npair, pj, head, b, S, past, nmb;
+    int64_t qrow0;                                // first token row of this sequence's queries in q / o
+    if constexpr (RAGGED) {
+        // segment of this workgroup: lane l compares with wg_end[l] (one vector load of the kernarg table, one ballot)
+        const int we = lane < AA.nseg ? AA.wg_end[lane] : 0x7fffffff;
+        const int sg = __builtin_popcountll(__builtin_amdgcn_ballot_w64(bid >= we));
+        const int wg0 = sg ? AA.wg_end[sg - 1] : 0;
+        const ObFlashSeg sgd = AA.seg[sg];
+        S = sgd.n; past = sgd.past; b = sgd.slot; qrow0 = sgd.row0;
+        nmb = (S + OB_FL_BM - 1) / OB_FL_BM;
+        npair = (nmb + 1) >> 1;
+        const int loc = bid - wg0;
+        pj = loc % npair; head = loc / npair;
+    } else {
+        S = A.S; past = A.past; nmb = A.nmb;
+        npair = (nmb + 1) >> 1;
+        pj = bid % npair;
+        const int bh = bid / npair;
+        head = bh % A.H; b = bh / A.H;
+        qrow0 = (int64_t)b * S;
+    }
     const int kvh = head / (A.H / A.Hkv);
-    const int S = A.S, L = A.past + S;
+    const int L = past + S;
     // K / V rows of this head as buffer resources: the offset of a piece is (lane-constant) + (block-uniform scalar), no per-block
     // address arithmetic, and rows beyond the last key read as zeros (they are masked; zeros keep 0 x V finite)
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.k + ((int64_t)b * A.Hkv + kvh) * A.max_len * D), 0, L * D * 2, 0x00020000);
@@ -137,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
 #endif
     for (int pass = 0; pass < 2; ++pass) {
     OB_FL_TP(0);
-    const int mb = pass == 0 ? A.nmb - 1 - pj : pj;
-    if (pass == 1 && mb == A.nmb - 1 - pj) break;               // odd count: the middle block has no partner
+    const int mb = pass == 0 ? nmb - 1 - pj : pj;
+    if (pass == 1 && mb == nmb - 1 - pj) break;                 // odd count: the middle block has no partner
     const int m0 = mb * OB_FL_BM;
     // Q^T fragments of the wave's two query tiles: lane (query = lr, d = 32 ds + 8 g .. + 7)
     ob_half8 qf[2][DK];
@@ -146,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int s = m0 + 32 * wave + 16 * qt + lr;
-        qpos[qt] = A.past + s;                                  // absolute position of this lane's query
-        const _Float16 *qr = A.q + (((int64_t)b * S + min(s, S - 1)) * A.H + head) * D;
+        qpos[qt] = past + s;                                    // absolute position of this lane's query
+        const _Float16 *qr = A.q + ((qrow0 + min(s, S - 1)) * A.H + head) * D;
 #pragma unroll
         for (int ds = 0; ds < DK; ++ds) qf[qt][ds] = *reinterpret_cast<const ob_half8 *>(qr + 32 * ds + 8 * g);
     }
@@ -159,9 +191,9 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
     // key blocks this workgroup needs: keys 0 .. past + min(m0 + 128, S) - 1
-    const int last_q = A.past + min(m0 + OB_FL_BM, S) - 1;
+    const int last_q = past + min(m0 + OB_FL_BM, S) - 1;
     const int nkb = last_q / OB_FL_BN + 1;
-    const int wave_last_q = A.past + min(m0 + 32 * wave + 31, S - 1);      // beyond it every key is masked for this wave
+    const int wave_last_q = past + min(m0 + 32 * wave + 31, S - 1);        // beyond it every key is masked for this wave
 
     // staging through registers: thread t moves piece t % NPC of rows t / NPC + RPL i
     ob_u32x4 kreg[KLD], vreg[KLD];
@@ -209,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
         OB_FL_T(0);
         const int k0 = kb * OB_FL_BN, buf = kb & 1;
         const bool active = !TAIL || k0 <= wave_last_q;     // (wave-uniform) otherwise every key of this block is masked for this wave
-        const bool diag = TAIL && (k0 + OB_FL_BN - 1 > A.past + m0 + 32 * wave || k0 + OB_FL_BN > L);
+        const bool diag = TAIL && (k0 + OB_FL_BN - 1 > past + m0 + 32 * wave || k0 + OB_FL_BN > L);
         const _Float16 *Kb = &Ks[buf][0][0], *Vb = &Vs[buf][0][0];
         const bool do_store = !(OB_FL_ABL & 2) && (!TAIL || kb + 1 < nkb);   // (past the last block the loads returned zeros: harmless)
         const bool do_load = !(OB_FL_ABL & 2) && (!TAIL || kb + 2 < nkb);
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
         OB_FL_T(4);
         __syncthreads();                        // block kb + 1 is complete in the other buffer; this one may be overwritten
     };
-    const int nfull = min((A.past + m0 + 1) / OB_FL_BN, nkb);   // blocks entirely below every wave's diagonal
+    const int nfull = min((past + m0 + 1) / OB_FL_BN, nkb);     // blocks entirely below every wave's diagonal
     load_block(0);
     store_block(0);
     load_block(1);
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void ob_flash_fwd_kernel(const ObFlashArgs 
         const float l = ob_fl_col_sum(l_run[qt]);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         if (s >= S) continue;
-        _Float16 *orow = A.o + (((int64_t)b * S + s) * A.H + head) * D;
+        _Float16 *orow = A.o + ((qrow0 + s) * A.H + head) * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             ob_half4 ov;

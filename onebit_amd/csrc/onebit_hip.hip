@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "../../include/onebit.h"
+#include "ob_host.h"
 #include "ob_linear.h"
 #include "ob_pack.h"
 #include "ob_decode.h"
@@ -41,7 +42,7 @@
 
 static thread_local char g_err[256] = "";
 
-static int ob_fail(int code, const char *fmt, ...)
+int ob_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -50,37 +51,15 @@ static int ob_fail(int code, const char *fmt, ...)
     return code;
 }
 
-static int ob_launch_status(const char *what)
+int ob_launch_status(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ob_fail((int)e, "%s: %s", what, hipGetErrorString(e));
     return 0;
 }
 
-static inline bool ob_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
-
-// Function attributes and device properties are per DEVICE, not per process: one process may
-// drive several GPUs (hipSetDevice between calls), so "already done" is keyed by the current device.
-#define OB_MAX_DEVICES 64
-static inline int ob_device_index()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OB_MAX_DEVICES) dev = 0;
-    return dev;
-}
-template <typename F>
-static inline void ob_set_max_lds_once(F kernel, bool (&done)[OB_MAX_DEVICES], int bytes)
-{
-    const int dev = ob_device_index();
-    if (!done[dev]) {
-        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        done[dev] = true;
-    }
-}
-
 extern "C" int onebit_abi_version(void) { return ONEBIT_ABI_VERSION; }
 
-static int ob_cu_count();
 // Test support: fill the LDS of every CU with `pattern` (LDS keeps its contents between launches).  The decode kernels multiply
 // digit images whose padding (chunks beyond K) must have been written by the launch itself; a test poisons the LDS first so that
 // a launch relying on stale zeros there produces garbage instead of passing by accident (advisor finding, round 4).
@@ -196,7 +175,6 @@ static void ob_launch_simple(const void *packed, int64_t ldw_bytes, const void *
                        (int)T, (int)K, (int)N);
 }
 
-static int ob_cu_count();
 static inline size_t ob_skinny_lds(int rt) { return OB_SKINNY_LDS(rt); }
 
 #ifdef OB_PROFILE_STAMPS
@@ -598,7 +576,7 @@ extern "C" int onebit_normalize_rows(const void *u, const float *mean, const flo
 
 // --------------------------------------------------------------- decode step --
 
-static int ob_cu_count()
+int ob_cu_count()
 {
     static int cus[OB_MAX_DEVICES] = {};
     const int dev = ob_device_index();
@@ -953,6 +931,30 @@ extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, cons
                        (int)max_len, (flags & ONEBIT_FLAG_Q_TOKEN_MAJOR) ? 1 : 0, ln_eps, row_stats};
     OB_LAUNCH_QKVROPE((int64_t)n_heads * head_dim, dim3((unsigned)(B * S)), (hipStream_t)stream, a);
     return ob_launch_status("rows_qkv_rope");
+}
+
+// Ragged rows (ABI 9): LayerNorm + RoPE + cache append for the token rows of SEVERAL sequences -- row t -> (row_slot[t], row_pos[t])
+extern "C" int onebit_rows_qkv_rope_ragged(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
+                                           const int32_t *row_slot, const int32_t *row_pos, void *q, void *k_cache, void *v_cache,
+                                           int64_t T, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots,
+                                           int64_t max_len, int64_t max_pos, float ln_eps, void *stream)
+{
+    if (T < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || n_slots <= 0 || max_len <= 0) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: bad size");
+    if (head_dim < 16 || (head_dim & (head_dim - 1)) != 0 || (int64_t)n_heads * head_dim > OB_DEC_MAXV * OB_DEC_THREADS * 8 || n_kv_heads > n_heads)
+        return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope_ragged: heads %d / %d x %d", n_heads, n_kv_heads, head_dim);
+    // positions are device-side: the kernel skips rows outside [0, max_len); the rope tables must cover every cache position
+    if (max_len > max_pos) return ob_fail(ONEBIT_E_SHAPE, "rows_qkv_rope_ragged: cache rows (%lld) beyond the rope tables (%lld)", (long long)max_len, (long long)max_pos);
+    if (T == 0) return 0;
+    if (!u_q || !u_k || !u_v || !cos || !sin || !q || !k_cache || !v_cache || !row_pos) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: null pointer");
+    if (!ob_aligned(u_q, 16) || !ob_aligned(u_k, 16) || !ob_aligned(u_v, 16) || !ob_aligned(q, 16) || !ob_aligned(k_cache, 16) || !ob_aligned(v_cache, 16) ||
+        !ob_aligned(cos, 16) || !ob_aligned(sin, 16))
+        return ob_fail(ONEBIT_E_ALIGN, "rows_qkv_rope_ragged: tensors must be 16-byte aligned");
+    if (T > 0x7fffffffLL || max_len > 0x7fffffffLL || n_slots > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: dimension too large");
+    ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
+                       (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, 1, n_heads, n_kv_heads, head_dim, 0,
+                       (int)max_len, 1, ln_eps, nullptr, row_slot, row_pos, (int)n_slots};
+    OB_LAUNCH_QKVROPE((int64_t)n_heads * head_dim, dim3((unsigned)T), (hipStream_t)stream, a);
+    return ob_launch_status("rows_qkv_rope_ragged");
 }
 
 // Tile partials: one slot per pre-LayerNorm vector of a layer (q, k, v, o, gate, up, down), each
@@ -1438,18 +1440,14 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     return ob_batched_head(m, st, s);
 }
 
-static int ob_batched_head(const onebit_model_t *m, const onebit_batch_state_t *st, hipStream_t s)
+int ob_lm_head_argmax(const void *x, const void *lm_head, void *logits, float *part_val, int32_t *part_idx, int32_t *next_tokens,
+                      int B, int H, int V, hipStream_t s)
 {
-    const int B = st->batch, H = m->hidden;
     int rc;
-    if (!st->next_tokens) return 0;
-    // batched lm_head + greedy sampling
-    if (!m->lm_head || m->vocab <= 0 || !st->part_val || !st->part_idx)
-        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: next_tokens needs model->lm_head, vocab and the part_val / part_idx scratch");
-    if (H % 64 != 0) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: lm_head needs hidden %% 64 == 0");
-    ObBHeadArgs ha = {(const _Float16 *)st->x, (const _Float16 *)m->lm_head, (_Float16 *)st->logits, st->part_val, st->part_idx,
-                      B, H, m->vocab};
-    const int hg = (m->vocab + OB_BH_ROWS - 1) / OB_BH_ROWS;
+    if (B < 1 || B > 64) return ob_fail(ONEBIT_E_SHAPE, "lm_head: %d rows outside 1..64", B);
+    if (H % 64 != 0) return ob_fail(ONEBIT_E_SHAPE, "lm_head needs hidden %% 64 == 0");
+    ObBHeadArgs ha = {(const _Float16 *)x, (const _Float16 *)lm_head, (_Float16 *)logits, part_val, part_idx, B, H, V};
+    const int hg = (V + OB_BH_ROWS - 1) / OB_BH_ROWS;
 #define OB_BH_GO(TT_)                                                                                              \
     do {                                                                                                           \
         const size_t lds = (size_t)2 * TT_ * 16 * OB_BH_PITCH * 2 + (size_t)8 * TT_ * 16 * 8;                      \
@@ -1461,10 +1459,65 @@ static int ob_batched_head(const onebit_model_t *m, const onebit_batch_state_t *
     else if (B <= 32) OB_BH_GO(2);
     else OB_BH_GO(4);
 #undef OB_BH_GO
-    if ((rc = ob_launch_status("decode_step_batched(lm_head)"))) return rc;
-    hipLaunchKernelGGL(ob_b_argmax_kernel, dim3(B), dim3(256), 0, s, (const float *)st->part_val, (const int *)st->part_idx, hg,
-                       m->vocab, st->next_tokens);
-    return ob_launch_status("decode_step_batched(argmax)");
+    if ((rc = ob_launch_status("lm_head"))) return rc;
+    hipLaunchKernelGGL(ob_b_argmax_kernel, dim3(B), dim3(256), 0, s, (const float *)part_val, (const int *)part_idx, hg, V, next_tokens);
+    return ob_launch_status("lm_head(argmax)");
+}
+
+static int ob_batched_head(const onebit_model_t *m, const onebit_batch_state_t *st, hipStream_t s)
+{
+    if (!st->next_tokens) return 0;
+    // batched lm_head + greedy sampling
+    if (!m->lm_head || m->vocab <= 0 || !st->part_val || !st->part_idx)
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: next_tokens needs model->lm_head, vocab and the part_val / part_idx scratch");
+    return ob_lm_head_argmax(st->x, m->lm_head, st->logits, st->part_val, st->part_idx, st->next_tokens, st->batch, m->hidden, m->vocab, s);
+}
+
+// ---- launchers the mixed step (onebit_mixed.hip) drives: ob_host.h ----
+int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s)
+{
+    if (c.T <= 0) return 0;
+    if (c.H <= 0 || c.H % 8 != 0 || c.H > OB_DEC_MAXV * OB_DEC_THREADS * 8 || c.n_scaled < 0 || c.n_scaled > 3 || c.T > 0x7fffffffLL)
+        return ob_fail(ONEBIT_E_SHAPE, "rows_norm: bad shape");
+    if (!c.rms_w || !c.hres_out || (!c.x && c.n_scaled == 0) || (c.embed ? !c.tokens : (!c.hres_in || !c.u_prev)))
+        return ob_fail(ONEBIT_E_ARG, "rows_norm: null pointer");
+    ObBNormArgs a = {};
+    a.embed = (const _Float16 *)c.embed; a.tokens = c.tokens; a.hres_in = (const _Float16 *)c.hres_in; a.u_prev = (const _Float16 *)c.u_prev;
+    a.bias_prev = (const _Float16 *)c.bias_prev; a.rms_w = (const _Float16 *)c.rms_w; a.hres_out = (_Float16 *)c.hres_out; a.x = (_Float16 *)c.x;
+    a.H = c.H; a.rms_eps = c.rms_eps; a.ln_eps = c.ln_eps; a.n_scaled = c.n_scaled; a.rows = c.rows;
+    for (int i = 0; i < c.n_scaled; ++i) {
+        if (!c.h_next[i] || !c.x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_norm: null scaled output %d", i);
+        a.h_next[i] = (const _Float16 *)c.h_next[i]; a.x_scaled[i] = (_Float16 *)c.x_scaled[i];
+    }
+    if (c.embed) OB_LAUNCH_NORM(true, c.H, dim3((unsigned)c.T), s, a);
+    else OB_LAUNCH_NORM(false, c.H, dim3((unsigned)c.T), s, a);
+    return ob_launch_status("rows_norm");
+}
+
+int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
+{
+    if (np < 1 || np > 3) return ob_fail(ONEBIT_E_ARG, "sk3_multi: 1..3 projections");
+    const int64_t K = ps[0]->K;
+    int64_t nn[3] = {0, 0, 0};
+    for (int i = 0; i < np; ++i) {
+        const onebit_proj_t &p = *ps[i];
+        if (!p.weight || !p.weight_scale || p.K != K || !us[i] || !as[i] || !ob_skinny3_shape_ok(p.weight, p.ldw_bytes, as[i], K, T, K, p.N))
+            return ob_fail(ONEBIT_E_SHAPE, "sk3_multi: projection %d is not eligible for the LDS-DMA skinny GEMM", i);
+        nn[i] = p.N;
+    }
+    const int rnt = ob_skinny3_pick_rnt(nn, np, 1);
+    ObSk3Args ka = {};
+    int wgs = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int j = i < np ? i : np - 1;
+        const onebit_proj_t &p = *ps[j];
+        if (i < np) wgs += (int)((p.N + 16 * rnt - 1) / (16 * rnt));
+        ka.p[i] = {(const uint32_t *)p.weight, (long long)(p.ldw_bytes / 4), (const _Float16 *)p.weight_scale, (const _Float16 *)as[j],
+                   (_Float16 *)us[j], nullptr, nullptr, (int)p.N, (int)K, wgs};
+    }
+    ka.lda = K; ka.T = (int)T;
+    if (!ob_launch_skinny3<false>(ka, wgs, rnt, s)) return ob_fail(ONEBIT_E_SHAPE, "sk3_multi: no skinny GEMM instance");
+    return ob_launch_status("sk3_multi");
 }
 
 extern "C" int onebit_fused_gemv(const onebit_proj_t *projs, void *const *outs, int nproj, int prologue,

@@ -73,6 +73,18 @@ class _KState(ctypes.Structure):      # onebit_kshard_state_t (ABI 8)
 KSEG_QKV, KSEG_ATTN_O, KSEG_GATE_UP, KSEG_DOWN, KSEG_HEAD = 0, 1, 2, 3, 4
 
 
+class _Seg(ctypes.Structure):         # onebit_seg_t (ABI 9)
+    _fields_ = [("row0", _i32), ("n", _i32), ("slot", _i32), ("past", _i32)]
+
+
+class _MixedState(ctypes.Structure):  # onebit_mixed_state_t (ABI 9)
+    _fields_ = [("struct_size", ctypes.c_uint64), ("n_rows", _i32), ("n_dec", _i32), ("n_seg", _i32), ("n_out", _i32),
+                ("n_slots", _i32), ("attn_chunk", _i32), ("dec_ctx", _i32),
+                ("tokens", _vp), ("row_slot", _vp), ("row_pos", _vp), ("segs", ctypes.POINTER(_Seg)), ("out_rows", _vp),
+                ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp),
+                ("workspace", _vp), ("workspace_bytes", ctypes.c_size_t)]
+
+
 class _FusedIn(ctypes.Structure):
     _fields_ = [("xin", _vp), ("embed", _vp), ("hres_in", _vp), ("u_prev", _vp), ("rms_w", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("token", _vp), ("hres_out", _vp),
@@ -434,3 +446,122 @@ class BatchedDecodeStep:
                                                      torch.cuda.current_stream(self.dev).cuda_stream)
         _lib.check(rc, "onebit_decode_step_batched")
         return self.buf["x"]
+
+
+class MixedStep:
+    """``onebit_mixed_step`` bound to a model and its KV-cache slots: ONE scheduler step of continuous batching (BASELINE config 5)
+    on native kernels -- the token rows of all scheduled items concatenated, every 1-bit projection one GEMM over all rows, fused
+    row glue, ragged attention (prompt chunks: causal flash attention with past; single-token rows: split-KV decode attention),
+    lm_head + greedy token on the last row of every item.  ``caches[l] = (k, v)``, ``[n_slots, n_kv_heads, max_len, head_dim]``
+    fp16.  The reference has no counterpart for the batching; per row the arithmetic is modeling_bitllama.py:869-918, 487-585."""
+
+    def __init__(self, model: OneBitLlamaForCausalLM, caches, n_slots: int, max_len: int, max_rows: int = 4096,
+                 attn_chunk: int = 256, keep_logits: bool = False):
+        cfg = model.config
+        if not model.lm_head.weight.is_cuda:
+            raise RuntimeError("MixedStep needs the model on a ROCm GPU (no CPU fallback)")
+        model = fp16_view(model)
+        p = model.lm_head.weight
+        H, D = cfg.hidden_size, cfg.head_dim
+        if D not in (64, 128) or H % 64 != 0 or cfg.num_attention_heads * D != H:
+            raise ValueError("MixedStep: head_dim must be 64 or 128 and hidden a multiple of 64")
+        if max_len > cfg.max_position_embeddings:
+            raise ValueError("max_len exceeds max_position_embeddings (the rope tables have that many rows)")
+        if any(pr.bias is not None for layer in model.model.layers for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj)):
+            raise ValueError("MixedStep: q / k / v biases (config.attention_bias) are not taken by the ragged rope kernel")
+        self.model, self.cfg, self.dev = model, cfg, p.device
+        self.n_slots, self.max_len, self.attn_chunk = int(n_slots), int(max_len), int(attn_chunk)
+        if -(-self.max_len // self.attn_chunk) > 64:
+            raise ValueError("MixedStep: attn_chunk too small for max_len (at most 64 splits)")
+        shape = (n_slots, cfg.num_key_value_heads, max_len, D)
+        for i, (kc, vc) in enumerate(caches):
+            if tuple(kc.shape) != shape or tuple(vc.shape) != shape or not kc.is_contiguous() or not vc.is_contiguous() or \
+                    kc.dtype != torch.float16 or vc.dtype != torch.float16 or kc.device != p.device or vc.device != p.device:
+                raise ValueError(f"cache {i} must be contiguous float16 {shape} on {p.device}")
+        self.lib = _lib.load()
+        self._model, self._keep = _model_struct(model, caches, max_len)
+        dev = self.dev
+        nparts = -(-cfg.vocab_size // 128) * 64
+        self._part_val = torch.zeros(nparts, dtype=torch.float32, device=dev)
+        self._part_idx = torch.zeros(nparts, dtype=torch.int32, device=dev)
+        self.keep_logits = keep_logits
+        self.logits = None
+        self.lib.onebit_mixed_workspace_bytes.argtypes = [ctypes.POINTER(_Model), _i64, _i32, _i32]
+        self.lib.onebit_mixed_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_MixedState), _vp]
+        self._rows = 0
+        self._ensure(int(max_rows))
+        self.launches = 0
+
+    def _ensure(self, rows: int):
+        """Room for a step of ``rows`` token rows (staging rows, workspace); grows geometrically, never shrinks."""
+        if rows <= self._rows:
+            return
+        rows = max(rows, 2 * self._rows, 64)
+        dev, ns = self.dev, self.n_slots
+        nb = int(self.lib.onebit_mixed_workspace_bytes(ctypes.byref(self._model), rows, ns, self.attn_chunk))
+        self._ws = None                                           # (free the old block first)
+        self._ws = torch.zeros(nb + 256, dtype=torch.uint8, device=dev)
+        self._ws_off = (-self._ws.data_ptr()) % 256
+        # one pinned staging row [tokens | row_slot | row_pos | out_rows] and ONE asynchronous copy per step; two of them in turn,
+        # each guarded by an event, so that a caller who enqueues steps without synchronising never rewrites a row in flight
+        self._h_stage = [torch.zeros(3 * rows + ns, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._h_np = [h.numpy() for h in self._h_stage]
+        self._h_ev = [None, None]
+        self._d_stage = [torch.zeros(3 * rows + ns, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.next_tokens = torch.zeros(ns, dtype=torch.int32, device=dev)
+        if self.keep_logits:
+            self.logits = torch.zeros(ns, self.cfg.vocab_size, dtype=torch.float16, device=dev)
+        self._rows = rows
+
+    @torch.no_grad()
+    def launch(self, items) -> torch.Tensor:
+        """Enqueue one step on the current stream.  ``items``: ``(slot, start, tokens)`` per scheduled request (distinct slots):
+        ``tokens`` enter the request's cache slot at positions ``start ...``.  Returns the device tensor of greedy next tokens,
+        one per item in the order given (the token after the item's LAST row: for a prompt chunk that is not the prompt's last one
+        the caller ignores it).  Asynchronous: synchronise before reading."""
+        n_items = len(items)
+        if n_items == 0 or n_items > self.n_slots:
+            raise ValueError(f"MixedStep.launch: {n_items} items for {self.n_slots} slots")
+        T = sum(len(it[2]) for it in items)
+        self._ensure(T)
+        R, ns, V = self._rows, self.n_slots, self.cfg.vocab_size
+        sb = self.launches & 1
+        if self._h_ev[sb] is not None:
+            self._h_ev[sb].synchronize()
+        st = self._h_np[sb]
+        tok, rs, rp, outr = st[:R], st[R:2 * R], st[2 * R:3 * R], st[3 * R:]
+        order = sorted(range(n_items), key=lambda i: len(items[i][2]) != 1)          # single-token rows first (stable)
+        segs, row, n_dec, dec_ctx, seen = [], 0, 0, 0, set()
+        for i in order:
+            slot, start, toks = items[i]
+            n = len(toks)
+            if n < 1 or not 0 <= slot < ns or start < 0 or start + n > self.max_len or slot in seen:
+                raise ValueError(f"MixedStep.launch: item {i} (slot {slot}, start {start}, {n} tokens) outside the cache or a repeated slot")
+            if min(toks) < 0 or max(toks) >= V:
+                raise ValueError(f"MixedStep.launch: item {i} has a token outside the vocabulary")
+            seen.add(slot)
+            tok[row:row + n] = toks
+            rs[row:row + n] = slot
+            rp[row:row + n] = range(start, start + n)
+            if n == 1:
+                n_dec += 1
+                dec_ctx = max(dec_ctx, start + 1)
+            else:
+                segs.append((row, n, slot, start))
+            outr[i] = row + n - 1
+            row += n
+        d = self._d_stage[sb]
+        d.copy_(self._h_stage[sb], non_blocking=True)                                # stream-ordered before the kernels
+        self._h_ev[sb] = torch.cuda.Event()
+        self._h_ev[sb].record(torch.cuda.current_stream(self.dev))
+        seg_arr = (_Seg * max(len(segs), 1))(*[_Seg(*g) for g in segs])
+        base = d.data_ptr()
+        state = _MixedState(ctypes.sizeof(_MixedState), T, n_dec, len(segs), n_items, ns, self.attn_chunk, dec_ctx,
+                            base, base + 4 * R, base + 8 * R, seg_arr, base + 12 * R, self.next_tokens.data_ptr(),
+                            None if self.logits is None else self.logits.data_ptr(), self._part_val.data_ptr(), self._part_idx.data_ptr(),
+                            self._ws.data_ptr() + self._ws_off, self._ws.numel() - self._ws_off)
+        with torch.cuda.device(self.dev):
+            rc = self.lib.onebit_mixed_step(ctypes.byref(self._model), ctypes.byref(state), torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "onebit_mixed_step")
+        self.launches += 1
+        return self.next_tokens[:n_items]

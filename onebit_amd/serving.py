@@ -216,6 +216,19 @@ class ContinuousBatcher:
                 self._native = BatchedDecodeStep(model, self.cache, max_batch, max_len)
             except ValueError:                  # shapes the C step does not take (e.g. in_features % 32 != 0)
                 self._native = None
+        # native MIXED step (onebit_mixed_step): every step that carries prompt tokens -- the workload that defines BASELINE
+        # config 5 -- runs on the HIP kernels (one GEMM per projection over all scheduled rows, fused row glue, ragged attention,
+        # lm_head on the sampling rows); `_forward` below (torch glue in the reference's op order) remains for native=False and
+        # for checkpoints the native step refuses (q / k / v biases, head_dim other than 64 / 128, fp32 parameters)
+        self._mixed = None
+        self.mixed_steps = 0
+        if native and self.dtype == torch.float16:
+            from .engine import MixedStep
+            try:
+                self._mixed = MixedStep(model, self.cache, max_batch, max_len, max_rows=max_step_tokens or 1024)
+                self._h_mixed = torch.zeros(max_batch, dtype=torch.int32).pin_memory()
+            except ValueError:
+                self._mixed = None
 
     @torch.no_grad()
     def _decode_static(self):
@@ -340,6 +353,14 @@ class ContinuousBatcher:
     def add_request(self, prompt: List[int], max_new_tokens: int) -> int:
         return self.sched.add(prompt, max_new_tokens)
 
+    def _mixed_step(self, items: List[Item]) -> List[int]:
+        """One step through ``onebit_mixed_step``: the greedy token after the last scheduled row of every item."""
+        nxt = self._mixed.launch([(it.req.slot, it.start, it.tokens) for it in items])
+        self._h_mixed[:len(items)].copy_(nxt, non_blocking=True)
+        torch.cuda.current_stream(self.dev).synchronize()                # the one host sync of the step
+        self.mixed_steps += 1
+        return self._h_mixed[:len(items)].tolist()
+
     @torch.no_grad()
     def _forward(self, items: List[Item]) -> torch.Tensor:
         """fp32 logits [len(items), vocab] of the last scheduled token of every item."""
@@ -425,6 +446,8 @@ class ContinuousBatcher:
                 nxt = [Item(it.req, [rows[j - 1][i]], it.start + j) for i, it in enumerate(items)]
                 done = done + self.sched.commit(nxt, rows[j])
             return done
+        if self._mixed is not None:
+            return self.sched.commit(items, self._mixed_step(items))
         logits = self._forward(items)
         return self.sched.commit(items, logits.argmax(-1).tolist())
 

@@ -8,7 +8,7 @@ if os.environ.get("OB_PROFILE_BUILD"):     # profiling build (-DOB_PROFILE_ABLAT
     so = "/tmp/libonebit_prof.so"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
                            "-DOB_PROFILE_ABLATE", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
-                           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
+                           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_mixed.hip")])
     _lib.LIB_PATH = so
 if os.environ.get("OB_LIB"):
     from onebit_amd import _lib

@@ -9,7 +9,7 @@ so = os.environ.get("OB_LIB") or "/tmp/libonebit_prof_%d.so" % os.getpid()
 if not os.environ.get("OB_LIB"):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
                        "-Wno-unused-value", "-DOB_PROFILE_STAMPS", *os.environ.get("OB_EXTRA", "").split(), "-o", so,
-                       os.path.join(ROOT, "onebit_amd/csrc/onebit_hip.hip")])
+                       os.path.join(ROOT, "onebit_amd/csrc/onebit_hip.hip"), os.path.join(ROOT, "onebit_amd/csrc/onebit_mixed.hip")])
 from onebit_amd import _lib
 _lib.LIB_PATH = so
 os.environ["OB_TIMING"] = "1"

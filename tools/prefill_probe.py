@@ -9,7 +9,7 @@ elif os.environ.get("OB_EXTRA"):
     import subprocess
     so = "/tmp/libonebit_exp.so"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
-                           *os.environ["OB_EXTRA"].split(), "-o", so, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip")])
+                           *os.environ["OB_EXTRA"].split(), "-o", so, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_hip.hip"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "onebit_amd/csrc/onebit_mixed.hip")])
     _lib.LIB_PATH = so
 dev = torch.device("cuda:0")
 lib = _lib.load()

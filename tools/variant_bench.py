@@ -13,17 +13,15 @@ VDIR = os.path.join(ROOT, "onebit_amd", "csrc", "variants")
 
 
 def build(specs):
+    """One library per variant through the package's own builder (all translation units, the variant's -D switches on each,
+    objects in a directory of the variant's own)."""
+    sys.path.insert(0, ROOT)
+    from onebit_amd import build as ob_build
     os.makedirs(VDIR, exist_ok=True)
-    procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
         out = os.path.join(VDIR, "libonebit_%s.so" % name)
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
-               *flags.split(), "-o", out, os.path.join(ROOT, "onebit_amd/csrc/onebit_hip.hip")]
-        procs.append((name, subprocess.Popen(cmd)))
-    for name, p in procs:
-        if p.wait():
-            sys.exit("build of variant %s failed" % name)
+        ob_build.build(force=True, lib=out, extra_flags=flags.split(), obj_dir=os.path.join(VDIR, "obj_" + name))
         print("built", name)
 
 
