@@ -429,6 +429,73 @@ def measure_continuous_batch(model, dev, slots=32, steps=40):
             "note": "steady-state decode, all slots active, greedy; per GPU"}
 
 
+def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, iters=8, requests=128, new_tokens=64):
+    """BASELINE config 5's defining workload ("32 sequences with mixed lengths, e.g. 8 prefill of 512 + 24 decode")
+    through onebit_mixed_step: (a) ONE step of `n_prefill` x `prompt` prompt tokens next to `slots - n_prefill` decoding requests
+    that each hold `ctx` cached tokens, HIP-event timed; (b) a closed-loop request stream (`requests` prompts of 64..`prompt`
+    tokens, `new_tokens` greedy tokens each, `slots` KV-cache slots, chunked prefill) through ContinuousBatcher: end-to-end
+    generated tokens/s and where the time went (steps with prompt tokens vs decode-only graph steps)."""
+    from onebit_amd.engine import MixedStep, fp16_view
+    from onebit_amd.serving import ContinuousBatcher
+    cfg = model.config
+    g = torch.Generator(device="cpu").manual_seed(11)
+    V = cfg.vocab_size
+    max_len = prompt + new_tokens + 64
+    n_dec = slots - n_prefill
+    caches = fp16_view(model).new_cache(slots, max_len).layers
+    ms = MixedStep(model, caches, slots, max_len, max_rows=n_prefill * prompt + n_dec)
+    rnd = lambda n: torch.randint(0, V, (n,), generator=g).tolist()
+    ms.launch([(s, 0, rnd(ctx)) for s in range(n_dec)])                       # the decoding requests' history
+    items = [(s, ctx, rnd(1)) for s in range(n_dec)] + [(n_dec + i, 0, rnd(prompt)) for i in range(n_prefill)]
+    rows = n_dec + n_prefill * prompt
+    for _ in range(2):
+        ms.launch(items)                                                       # (the same cache rows are rewritten: idempotent)
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        ms.launch(items)
+        ev[i + 1].record()
+    torch.cuda.synchronize(dev)
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    med = ts[len(ts) // 2]
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    w1 = L * (4 * H * H + 3 * H * I)
+    step = {"decode_rows": n_dec, "decode_context": ctx, "prefill_segments": n_prefill, "prefill_tokens_each": prompt, "rows": rows,
+            "ms": round(med, 3), "ms_min": round(ts[0], 3), "iterations": iters, "tokens_per_s": round(rows / med * 1e3, 1),
+            "onebit_layer_TFLOPs_equivalent": round(2.0 * rows * w1 / med / 1e9, 1),
+            "launches_per_layer": "norm, q, k, v, rope, flash (prompt chunks), split-KV (decode rows), o, norm, gate, up, swiglu, down = 13",
+            "engine": "onebit_mixed_step"}
+    del ms, caches
+    torch.cuda.empty_cache()
+    # (b) the request stream
+    lens = torch.randint(64, prompt + 1, (requests,), generator=g).tolist()
+    cb = ContinuousBatcher(model, max_batch=slots, max_len=max_len, prefill_chunk=prompt, max_step_tokens=n_prefill * prompt + slots)
+    for n in lens[:4]:                                                         # warm-up: graph capture, lazy initialisation
+        cb.add_request(rnd(n), 4)
+    cb.run()
+    cb.steps = cb.mixed_steps = cb.graph_steps = cb.tokens_scheduled = 0
+    cb.time_mixed = cb.time_decode = 0.0
+    for n in lens:
+        cb.add_request(rnd(n), new_tokens)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = cb.run()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gen = sum(len(v) for v in out.values()) - 4 * 4
+    stream = {"requests": requests, "prompt_tokens": "64..%d (mean %.0f)" % (prompt, sum(lens) / len(lens)), "new_tokens_each": new_tokens,
+              "slots": slots, "prefill_chunk": prompt, "max_step_tokens": n_prefill * prompt + slots, "wall_s": round(dt, 3),
+              "generated_tokens_per_s": round(gen / dt, 1), "all_tokens_per_s": round((gen + sum(lens)) / dt, 1),
+              "steps": cb.steps, "steps_with_prompt_tokens": cb.mixed_steps, "decode_only_graph_steps": cb.graph_steps,
+              "time_share_mixed_steps": round(cb.time_mixed / max(cb.time_mixed + cb.time_decode, 1e-9), 3),
+              "time_share_decode_steps": round(cb.time_decode / max(cb.time_mixed + cb.time_decode, 1e-9), 3),
+              "ms_per_mixed_step": round(cb.time_mixed / max(cb.mixed_steps, 1) * 1e3, 2),
+              "ms_per_decode_step": round(cb.time_decode / max(cb.graph_steps, 1) * 1e3, 3),
+              "engine": "onebit_mixed_step + onebit_decode_step_batched (HIP graph)" if cb._mixed is not None and cb._native is not None else "torch glue"}
+    return {"step": step, "request_stream": stream, "per": "GPU", "data": "synthetic"}
+
+
 def measure_prefill_model(model, dev, B=8, S=2048):
     """BASELINE configs[2]: whole-model prefill of B x S tokens (1-bit GEMMs + fused row glue +
     the vendor's fused attention), tokens/s and the 1-bit layers' share expressed in TFLOP/s."""
@@ -693,6 +760,7 @@ class Hooks:
     measure_roofline = staticmethod(measure_roofline)
     measure_prefill_sharded = staticmethod(measure_prefill_sharded)
     measure_continuous_batch = staticmethod(measure_continuous_batch)
+    measure_mixed_step = staticmethod(measure_mixed_step)
     measure_prefill_model = staticmethod(measure_prefill_model)
     measure_prefill_model_tp = staticmethod(measure_prefill_model_tp)
     measure_k_sharded_decode = staticmethod(measure_k_sharded_decode)
@@ -832,6 +900,11 @@ def main(argv=None, hooks=None):
             hk.empty_cache()
             m13 = hk.build_model(model_config("13b"), 4242, dev)
             serve["llama2_13b_shapes"] = hk.measure_continuous_batch(m13, dev)
+            try:                                # config 5's defining workload: prompt chunks next to decoding requests, native step
+                serve["mixed"] = hk.measure_mixed_step(m13, dev)
+                serve["mixed"]["model"] = "LLaMA2-13B shapes"
+            except Exception as e:
+                serve["mixed"] = {"error": "%s: %s" % (type(e).__name__, e)}
             del m13
             hk.empty_cache()
         except Exception as e:

@@ -271,6 +271,14 @@ typedef struct onebit_decode_state {
      * PERFORMANCE hint for steps the host knows to be at a position < 64 -- results do not depend on it at any position.
      * 0 / 128: the 128-position window.                                                                              */
     int32_t attn_blind;
+    /* ABI 9, optional: attn_chunk > 0 (a multiple of 64) with q_rows set selects the KEY-BLOCK form of the long-context attention:
+     * one launch normalises / rotates q, k, v and appends to the cache (onebit_rows_qkv_rope_ragged), one launch streams the
+     * context as attn_splits workgroups of attn_chunk positions per head with an in-launch last-arriver combine
+     * (onebit_attention_decode_rows; attn_scratch then holds onebit_attention_decode_scratch_bytes(1, n_heads, attn_splits) bytes,
+     * zero-filled once) -- K and V are each read once, no score scratch; attn_splits * attn_chunk must cover the context + 1.
+     * attn_chunk == 0: the round-2 pair (scores kernel + P.V kernel, exact fp16 probabilities).  No q / k / v bias.       */
+    int32_t attn_chunk;
+    void *q_rows;               /* fp16 [n_heads * head_dim]                                                               */
 } onebit_decode_state_t;
 
 size_t onebit_attn_scratch_bytes(const onebit_model_t *model, int32_t splits);
@@ -323,6 +331,18 @@ typedef struct onebit_batch_state {
      * capture), one lm_head over all rows.  Per-row results do not depend on the grouping.  The side streams are created
      * on the first such call, which must not be inside a stream capture.                                            */
     int32_t chains;
+    /* ABI 9: attention over KEY BLOCKS for contexts of any length.  attn_splits >= 1 with q_rows (and, for attn_splits > 1,
+     * attn_scratch) set: per layer the q | k | v rows go through onebit_rows_qkv_rope_ragged (LayerNorm + RoPE + cache append, one
+     * workgroup per slot) into q_rows and the attention runs as onebit_attention_decode_rows: (head, slot, split) workgroups of
+     * attn_chunk positions each, combined by the last arriver -- 9 launches per layer instead of 8, no bound on max_len, and a
+     * 512-token context is streamed by 2-8 workgroups per (head, slot) instead of one.  attn_splits * attn_chunk must cover the
+     * longest context of the step (+ 1); a caller that knows its positions sizes it per step (or per captured graph).
+     * attn_splits == 0: one workgroup per (head, slot) keeps every score in LDS (the fast form up to a few hundred positions;
+     * 4 * max_len + 5.4 KB of LDS <= 64 KB).  Not combined with chains > 1.                                                  */
+    int32_t attn_splits;
+    int32_t attn_chunk;         /* positions per split, a multiple of 64 (0: 256)                                            */
+    void *q_rows;               /* fp16 [B, n_heads * head_dim]                                                             */
+    void *attn_scratch;         /* onebit_attention_decode_scratch_bytes(B, n_heads, attn_splits) bytes, zero-filled once   */
 } onebit_batch_state_t;
 
 size_t onebit_batch_stats_floats(const onebit_model_t *model, int32_t batch);

@@ -1279,7 +1279,21 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         at.pos = st->pos; at.H = m->n_heads; at.Hkv = m->n_kv_heads; at.D = D; at.max_len = m->max_len;
         at.ln_eps = m->ln_eps;
         const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
-        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the attention kernel", m->max_len);
+        if (st->attn_splits > 0) {
+            // key-block form (ABI 9): LayerNorm + RoPE + cache append per slot, then (head, slot, split) workgroups
+            const void *h_o = sk3 ? L.o.input_factor : nullptr;
+            if (L.q_bias || L.k_bias || L.v_bias)
+                return ob_fail(ONEBIT_E_ARG, "decode_step_batched: attn_splits with q / k / v biases (layer %d): use attn_splits = 0", l);
+            const int chunk = st->attn_chunk > 0 ? st->attn_chunk : 256;
+            if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, at.kcache, at.vcache,
+                                                  B, m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, m->ln_eps, s)))
+                return rc;
+            if ((rc = onebit_attention_decode_rows(st->q_rows, at.kcache, at.vcache, st->attn_out, h_o, nullptr, st->pos, B, m->n_heads, m->n_kv_heads, D,
+                                                   B, m->max_len, chunk, st->attn_splits, st->attn_scratch,
+                                                   onebit_attention_decode_scratch_bytes(B, m->n_heads, st->attn_splits), s)))
+                return rc;
+        } else {
+        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the one-workgroup attention kernel (set attn_splits)", m->max_len);
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
         static const int battn = getenv("OB_BATCH_ATTN_THREADS") ? atoi(getenv("OB_BATCH_ATTN_THREADS")) : 256;
         if (attn_pst) { at.st_q = qs.s[0]; at.st_k = qs.s[1]; at.st_v = qs.s[2]; }
@@ -1302,6 +1316,7 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         else if (battn == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 256, false>), dim3(m->n_heads, B), dim3(256), attn_lds, s, at, ObPfPlan{});
         else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, false>), dim3(m->n_heads, B), dim3(512), attn_lds, s, at, ObPfPlan{});
         if ((rc = ob_launch_status("decode_step_batched(attn)"))) return rc;
+        }
         // 4. o_proj
         if (sk3) { if ((rc = launch_sk3(g_o, "o"))) return rc; }
         else if (splitk_o) { if ((rc = gemm_splitk2(L.o, st->attn_out, NQ, zs0, zs1, "o"))) return rc; }
@@ -1388,6 +1403,9 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
         !st->hres0 || !st->hres1 || !st->x || !st->act || !st->u_q || !st->u_k || !st->u_v || !st->attn_out ||
         !st->u_o || !st->u_gate || !st->u_up || !st->u_down)
         return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer");
+    if (st->attn_splits < 0 || (st->attn_splits > 0 && (!st->q_rows || (st->attn_splits > 1 && !st->attn_scratch) ||
+                                                         (st->attn_chunk != 0 && (st->attn_chunk < 64 || st->attn_chunk % 64 != 0)))))
+        return ob_fail(ONEBIT_E_ARG, "decode_step_batched: attn_splits needs q_rows, attn_scratch (splits > 1) and attn_chunk a multiple of 64");
     hipStream_t s = (hipStream_t)stream;
     const int B = st->batch, H = m->hidden, I = m->intermediate;
     const int NQ = m->n_heads * m->head_dim, NK = m->n_kv_heads * m->head_dim;
@@ -1400,6 +1418,7 @@ extern "C" int onebit_decode_step_batched(const onebit_model_t *m, const onebit_
     int chains = chains_env > 0 ? chains_env : (st->chains > 0 ? st->chains : 1);
     if (chains > 4) chains = 4;
     while (chains > 1 && B / chains < 2) --chains;
+    if (st->attn_splits > 0) chains = 1;             // (the split attention's scratch is laid out for all B rows of one chain)
     int rc;
     if (chains <= 1) {
         if ((rc = ob_batched_layers(m, st, 0, s))) return rc;
@@ -1570,6 +1589,15 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
     // tile_stats == NULL: every consumer recomputes its LayerNorm statistics from the vectors -- the kernels' non-PST forms
     if (st->tile_stats && !ob_aligned(st->tile_stats, 16))
         return ob_fail(ONEBIT_E_ALIGN, "decode_step: tile_stats must be 16-byte aligned");
+    // (every flag is validated HERE, before the first launch: a bad value must not leave a half-issued step or a half-built capture)
+    if (st->attn_blind != 0 && st->attn_blind != 64 && st->attn_blind != 128)
+        return ob_fail(ONEBIT_E_FLAG, "decode_step: attn_blind %d (0, 64 or 128)", st->attn_blind);
+    static const int blind_env = getenv("OB_ATTN_BLIND") ? atoi(getenv("OB_ATTN_BLIND")) : 0;      // A/B override: 64 / 128
+    if (blind_env != 0 && blind_env != 64 && blind_env != 128)
+        return ob_fail(ONEBIT_E_FLAG, "decode_step: OB_ATTN_BLIND=%d (64 or 128)", blind_env);
+    const bool keyblock = st->attn_chunk > 0;
+    if (keyblock && (st->attn_chunk % 64 != 0 || st->attn_splits < 1 || st->attn_splits > 64 || !st->q_rows || (st->attn_splits > 1 && !st->attn_scratch)))
+        return ob_fail(ONEBIT_E_ARG, "decode_step: attn_chunk %d needs a multiple of 64, 1..64 attn_splits, q_rows and (splits > 1) attn_scratch", st->attn_chunk);
     hipStream_t s = (hipStream_t)stream;
     const int H = m->hidden, I = m->intermediate, D = m->head_dim;
     _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
@@ -1605,7 +1633,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         a.rms_w = (const _Float16 *)L.input_layernorm_w;
         a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
         // single-launch attention only (the split-KV kernels read the position first anyway)
-        const bool rope_cur = st->rope_cur && !(st->attn_splits > 1 && st->attn_scratch);
+        const bool rope_cur = st->rope_cur && !(st->attn_splits > 1 && st->attn_scratch) && !keyblock;
         if (l == 0 && rope_cur) {
             a.rope_pos = st->pos; a.rope_cos = (const _Float16 *)m->rope_cos; a.rope_sin = (const _Float16 *)m->rope_sin;
             a.rope_out = (_Float16 *)st->rope_cur; a.rope_D = D; a.rope_max = m->max_len;
@@ -1626,7 +1654,16 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         at.st_q = ts_q; at.st_k = ts_k; at.st_v = ts_v;
         if (rope_cur) at.rope_cur = (const _Float16 *)st->rope_cur;
         at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
-        if (st->attn_splits > 1 && st->attn_scratch) {
+        if (keyblock) {
+            if (qkv_bias) return ob_fail(ONEBIT_E_ARG, "decode_step: the key-block attention takes no q / k / v bias (layer %d): use attn_chunk = 0", l);
+            if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, L.k_cache, L.v_cache,
+                                                  1, m->n_heads, m->n_kv_heads, D, 1, m->max_len, m->max_len, m->ln_eps, s)))
+                return rc;
+            if ((rc = onebit_attention_decode_rows(st->q_rows, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads, m->n_kv_heads, D,
+                                                   1, m->max_len, st->attn_chunk, st->attn_splits, st->attn_scratch,
+                                                   onebit_attention_decode_scratch_bytes(1, m->n_heads, st->attn_splits), s)))
+                return rc;
+        } else if (st->attn_splits > 1 && st->attn_scratch) {
             const int S = st->attn_splits;
             if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);
             ObAttnSplitArgs sp = {};
@@ -1651,13 +1688,10 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
             // leave idle: 986-989 -> 1004 tok/s on one box, alternating runs.  (The same for gate|up's 11 MB, or from the
             // GEMV launches' tails, loses: DESIGN.md section 6.)
             static const int attn_pf_env = getenv("OB_DEC_PREFETCH_O") ? atoi(getenv("OB_DEC_PREFETCH_O")) : 1;
-            static const int blind_env = getenv("OB_ATTN_BLIND") ? atoi(getenv("OB_ATTN_BLIND")) : 0;      // A/B override: 64 / 128
             const bool blind64 = (blind_env ? blind_env : st->attn_blind) == 64;
             ObPfPlan apf = {};
             if (attn_pf_env && m->n_heads < ob_cu_count()) apf = ob_dec_gemv_plan(o);
             const int agrid = apf.nseg ? ob_cu_count() : m->n_heads;
-            if (st->attn_blind != 0 && st->attn_blind != 64 && st->attn_blind != 128)
-                return ob_fail(ONEBIT_E_FLAG, "decode_step: attn_blind %d (0, 64 or 128)", st->attn_blind);
             if (qkv_bias) {         // config.attention_bias: the BIAS instances (q / k / v = fp16(LayerNorm(u) + b) before RoPE)
                 if (at.st_q && attn_threads == 256 && blind64) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true, false, 64>), dim3(agrid), dim3(256), attn_lds, s, at, apf);
                 else if (at.st_q && attn_threads == 256) hipLaunchKernelGGL((ob_dec_attn_kernel<true, 256, true, true>), dim3(agrid), dim3(256), attn_lds, s, at, apf);

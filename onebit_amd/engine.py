@@ -50,7 +50,8 @@ class _State(ctypes.Structure):
                 ("hres0", _vp), ("hres1", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp),
                 ("attn_out", _vp), ("u_o", _vp), ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("attn_splits", _i32), ("attn_scratch", _vp),
-                ("tile_stats", _vp), ("rope_cur", _vp), ("attn_blind", _i32)]
+                ("tile_stats", _vp), ("rope_cur", _vp), ("attn_blind", _i32),
+                ("attn_chunk", _i32), ("q_rows", _vp)]                                   # ABI 9: key-block long-context attention
 
 
 class _BatchState(ctypes.Structure):
@@ -58,7 +59,8 @@ class _BatchState(ctypes.Structure):
                 ("act", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp), ("u_o", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("u_down", _vp),
                 ("next_tokens", _vp), ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("qkv_stats", _vp),
-                ("x_scaled", _vp), ("chains", _i32)]
+                ("x_scaled", _vp), ("chains", _i32),
+                ("attn_splits", _i32), ("attn_chunk", _i32), ("q_rows", _vp), ("attn_scratch", _vp)]      # ABI 9: key-block attention
 
 
 class _KState(ctypes.Structure):      # onebit_kshard_state_t (ABI 8)
@@ -196,9 +198,16 @@ def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int, krange=No
 
 class DecodeEngine:
     def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True,
-                 long_context_from: int = 384, attn_splits: int = 8):
-        """``long_context_from``: position from which a step uses the split-KV attention graph (two
-        launches per layer over head x split); below it one workgroup per head is faster.  0 disables."""
+                 long_context_from: int = 384, attn_splits: int = 8, long_attention: str = "keyblock", attn_chunk: int = 128):
+        """``long_context_from``: position from which a step uses a split-KV attention graph (two launches per layer over
+        head x split); below it one workgroup per head is faster.  0 disables.
+        ``long_attention``: "keyblock" (round 6, default: LayerNorm + RoPE + cache append in one launch, then
+        ``onebit_attention_decode_rows`` -- ``attn_chunk`` positions per workgroup, K and V read once, last-arriver combine; one
+        HIP graph per power-of-two split count, chosen per step by the host-known position) or "pair" (round 2: scores kernel +
+        P.V kernel with ``attn_splits`` splits, the reference's fp16 probability rounding; also what a checkpoint with
+        q / k / v biases takes)."""
+        if long_attention not in ("keyblock", "pair"):
+            raise ValueError("long_attention must be 'keyblock' or 'pair'")
         cfg = model.config
         if not model.lm_head.weight.is_cuda:
             raise RuntimeError("DecodeEngine needs the model on a ROCm GPU (no CPU fallback)")
@@ -228,7 +237,7 @@ class DecodeEngine:
                              b["hres0"].data_ptr(), b["hres1"].data_ptr(), b["u_q"].data_ptr(), b["u_k"].data_ptr(),
                              b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(), b["u_gate"].data_ptr(),
                              b["u_up"].data_ptr(), b["u_down"].data_ptr(), b["logits"].data_ptr(),
-                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None, None, 0)
+                             b["part_val"].data_ptr(), b["part_idx"].data_ptr(), 0, None, None, None, 0, 0, None)
         self._rope_cur = z(2 * D)
         self._state.rope_cur = self._rope_cur.data_ptr()
         self.lib.onebit_decode_stats_floats.restype = ctypes.c_size_t
@@ -265,7 +274,40 @@ class DecodeEngine:
                         self.graph64 = g
                     else:
                         self.graph = g
-        if self._long_from:
+        has_bias = any(pr.bias is not None for layer in model.model.layers
+                       for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj))
+        self._keyblock = long_attention == "keyblock" and not has_bias and bool(self._long_from)
+        self._kb_graphs, self._kb_states = {}, {}
+        if self._keyblock:
+            # one state / graph per power-of-two split count: splits * attn_chunk covers the step's context + 1
+            if attn_chunk < 64 or attn_chunk % 64:
+                raise ValueError("attn_chunk must be a positive multiple of 64")
+            self._kb_chunk = int(attn_chunk)
+            top = -(-self.max_len // self._kb_chunk)
+            if top > 64:
+                self._kb_chunk = 64 * -(-self.max_len // (64 * 64))          # at most 64 splits: widen the chunk
+                top = -(-self.max_len // self._kb_chunk)
+            self._q_rows = z(Hq)
+            self.lib.onebit_attention_decode_scratch_bytes.restype = ctypes.c_size_t
+            ns = 1
+            while True:
+                nb = int(self.lib.onebit_attention_decode_scratch_bytes(1, cfg.num_attention_heads, ns))
+                scratch = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
+                stt = _State.from_buffer_copy(self._state)
+                stt.attn_splits, stt.attn_chunk, stt.q_rows, stt.attn_scratch = ns, self._kb_chunk, self._q_rows.data_ptr(), scratch.data_ptr()
+                self._kb_states[ns] = (stt, scratch)
+                self.pos.zero_()
+                self._launch(state=stt)
+                torch.cuda.synchronize(dev)
+                if use_graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._launch(state=stt)
+                    self._kb_graphs[ns] = g
+                if ns >= top:
+                    break
+                ns *= 2
+        elif self._long_from:
             S = max(2, min(int(attn_splits), 16, self.max_len // 128))
             self.lib.onebit_attn_scratch_bytes.restype = ctypes.c_size_t
             self.lib.onebit_attn_scratch_bytes.argtypes = [ctypes.POINTER(_Model), ctypes.c_int]
@@ -285,8 +327,15 @@ class DecodeEngine:
         self.pos.zero_()
         self.token.zero_()
 
-    def _launch(self, long: bool = False, blind64: bool = False):
-        st = self._state_long if long else (self._state64 if blind64 else self._state)
+    def _kb_splits(self, ctx: int) -> int:
+        """Power-of-two split count whose splits * attn_chunk positions cover a context of ``ctx`` tokens."""
+        ns = 1
+        while ns * self._kb_chunk < ctx and ns * 2 in self._kb_states:
+            ns *= 2
+        return ns
+
+    def _launch(self, long: bool = False, blind64: bool = False, state=None):
+        st = state if state is not None else (self._state_long if long else (self._state64 if blind64 else self._state))
         with torch.cuda.device(self.dev):
             rc = self.lib.onebit_decode_step(ctypes.byref(self._model), ctypes.byref(st),
                                              torch.cuda.current_stream(self.dev).cuda_stream)
@@ -328,6 +377,15 @@ class DecodeEngine:
             raise RuntimeError(f"DecodeEngine.step: KV cache full ({self.max_len} positions); build the engine with a larger max_len")
         long = bool(self._long_from) and (self._steps >= self._long_from or not self._short_ok)
         b64 = not long and self._steps < 64
+        if long and self._keyblock:
+            ns = self._kb_splits(self._steps + 1)                  # this step attends to positions 0 .. _steps
+            g = self._kb_graphs.get(ns)
+            if g is not None:
+                g.replay()
+            else:
+                self._launch(state=self._kb_states[ns][0])
+            self._steps += 1
+            return
         g = self.graph_long if long else (self.graph64 if b64 else self.graph)
         if g is not None:
             g.replay()
@@ -373,7 +431,11 @@ class BatchedDecodeStep:
     ``fp16_view(model).new_cache(B, max_len)`` (the model's own ``new_cache`` would be fp32 and is refused)."""
 
     def __init__(self, model: OneBitLlamaForCausalLM, caches, batch: int, max_len: int, sample: bool = True,
-                 keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True, chains: int = 0):
+                 keep_logits: bool = False, producer_stats: bool = True, prescaled_rows: bool = True, chains: int = 0,
+                 attn_splits: int = 0, attn_chunk: int = 256):
+        """``attn_splits`` > 0: attention over key blocks (``onebit_attention_decode_rows``: ``attn_splits`` workgroups of
+        ``attn_chunk`` positions per (head, slot)) -- any ``max_len``, and the form to use once contexts pass a few hundred
+        positions; ``attn_splits * attn_chunk`` must cover the longest context + 1.  0: one workgroup per (head, slot)."""
         cfg = model.config
         if not model.lm_head.weight.is_cuda:
             raise RuntimeError("BatchedDecodeStep needs the model on a ROCm GPU (no CPU fallback)")
@@ -424,7 +486,15 @@ class BatchedDecodeStep:
                                   b["hres1"].data_ptr(), b["x"].data_ptr(), b["act"].data_ptr(), b["u_q"].data_ptr(),
                                   b["u_k"].data_ptr(), b["u_v"].data_ptr(), b["attn_out"].data_ptr(), b["u_o"].data_ptr(),
                                   b["u_gate"].data_ptr(), b["u_up"].data_ptr(), b["u_down"].data_ptr(), nt, lg, pv, pi, None, None,
-                                  int(chains))
+                                  int(chains), 0, 0, None, None)
+        if attn_splits:
+            if attn_chunk < 64 or attn_chunk % 64 or attn_splits < 1:
+                raise ValueError("attn_chunk must be a positive multiple of 64, attn_splits >= 1")
+            self._q_rows = z(batch, Hq)
+            nb = int(self.lib.onebit_attention_decode_scratch_bytes(batch, cfg.num_attention_heads, int(attn_splits)))
+            self._attn_scratch = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
+            self._state.attn_splits, self._state.attn_chunk = int(attn_splits), int(attn_chunk)
+            self._state.q_rows, self._state.attn_scratch = self._q_rows.data_ptr(), self._attn_scratch.data_ptr()
         # room for the consumers' pre-scaled rows fp16(x * input_factor): the projections then take the LDS-DMA skinny GEMM
         if prescaled_rows:
             self._x_scaled = torch.zeros(3, batch, H, dtype=f16, device=dev)

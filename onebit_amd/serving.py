@@ -19,6 +19,7 @@ GPU, weights replicated: 0.8-1.6 GB); there is no data-path collective to add.
 from __future__ import annotations
 
 import math
+import time
 from collections import deque
 from dataclasses import dataclass, field
 from typing import Deque, Dict, List, Optional, Tuple
@@ -167,7 +168,11 @@ class Scheduler:
 class ContinuousBatcher:
     def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
                  max_step_tokens: Optional[int] = None, use_graph: bool = True, native: bool = True,
-                 prefill_chunk: Optional[int] = None, max_burst: int = 1):
+                 prefill_chunk: Optional[int] = None, max_burst: int = 1, long_context_from: int = 256, attn_chunk: int = 512):
+        """``long_context_from``: a decode-only step whose longest context exceeds it replays the graph of the KEY-BLOCK attention
+        (``onebit_decode_step_batched`` with ``attn_splits``: ``attn_chunk`` positions per workgroup, one graph per power-of-two
+        split count) instead of the one-workgroup-per-(head, slot) form -- measured crossover at 32 slots on 7B ~256 positions
+        (tools/serve_ctx_probe.py), and the only form once 4 * max_len + 5.4 KB of scores no longer fit the LDS."""
         p = model.lm_head.weight
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")
@@ -210,10 +215,17 @@ class ContinuousBatcher:
         self.graph_steps = 0
         # native batched step (onebit_decode_step_batched) for the decode-only graph; torch-op glue otherwise
         self._native = None
+        self._long = {}                         # split count -> (BatchedDecodeStep with attn_splits, its HIP graph)
+        self.long_context_from, self.attn_chunk = int(long_context_from), int(attn_chunk)
+        self._short_ok = 512 + 3 * 128 * 2 + 8 * 128 * 4 + 4 * max_len <= 64 * 1024       # the one-workgroup form's LDS bound
+        self.long_steps = 0
         if native and use_graph and 2 <= max_batch <= 64 and self.dtype == torch.float16 and cfg.head_dim <= 128:
             from .engine import BatchedDecodeStep
             try:
-                self._native = BatchedDecodeStep(model, self.cache, max_batch, max_len)
+                if self._short_ok:
+                    self._native = BatchedDecodeStep(model, self.cache, max_batch, max_len)
+                else:
+                    self._native = self._long_engine(-(-max_len // self.attn_chunk))
             except ValueError:                  # shapes the C step does not take (e.g. in_features % 32 != 0)
                 self._native = None
         # native MIXED step (onebit_mixed_step): every step that carries prompt tokens -- the workload that defines BASELINE
@@ -222,6 +234,7 @@ class ContinuousBatcher:
         # for checkpoints the native step refuses (q / k / v biases, head_dim other than 64 / 128, fp32 parameters)
         self._mixed = None
         self.mixed_steps = 0
+        self.time_mixed = self.time_decode = 0.0     # wall seconds in steps with / without prompt tokens (each step ends in a host sync)
         if native and self.dtype == torch.float16:
             from .engine import MixedStep
             try:
@@ -230,17 +243,45 @@ class ContinuousBatcher:
             except ValueError:
                 self._mixed = None
 
+    def _long_engine(self, splits: int):
+        """The native step with key-block attention for ``splits`` splits of ``attn_chunk`` positions (built on first use)."""
+        from .engine import BatchedDecodeStep
+        if splits not in self._long:
+            has_bias = any(pr.bias is not None for layer in self.model.model.layers
+                           for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj))
+            if has_bias:
+                raise ValueError("key-block attention takes no q / k / v bias")
+            self._long[splits] = [BatchedDecodeStep(self.model, self.cache, self.sched.max_batch, self.sched.max_len,
+                                                    attn_splits=splits, attn_chunk=self.attn_chunk), None]
+        return self._long[splits][0]
+
+    def _engine_for(self, ctx: int):
+        """(engine, graph key) for a decode-only step whose longest context is ``ctx`` tokens; key 0 = the short form."""
+        if self._native is None:
+            return None, 0
+        if self._short_ok and (ctx <= self.long_context_from or self.long_context_from <= 0):
+            return self._native, 0
+        ns = 1
+        while ns * self.attn_chunk < ctx:
+            ns *= 2
+        ns = min(ns, max(1, 1 << (-(-self.sched.max_len // self.attn_chunk) - 1).bit_length()))
+        try:
+            return self._long_engine(ns), ns
+        except ValueError:
+            return self._native, 0
+
     @torch.no_grad()
-    def _decode_static(self):
+    def _decode_static(self, eng=None):
         """One token for every slot (static shapes, no host-side shape dependence): the same
         arithmetic as the batched decode branch of ``_forward`` with Lmax = max_len."""
-        if self._native is not None:
+        eng = eng if eng is not None else self._native
+        if eng is not None:
             # idle slots keep pos = -1: their rows are computed, attention / cache append skipped
-            self._native.tokens.copy_(self._g_ids)
-            self._native.pos.copy_(self._g_pos_native)
-            x = self._native.launch()
-            if self._native.next_tokens is not None:              # lm_head + argmax ran inside the C step
-                self._g_next.copy_(self._native.next_tokens)
+            eng.tokens.copy_(self._g_ids)
+            eng.pos.copy_(self._g_pos_native)
+            x = eng.launch()
+            if eng.next_tokens is not None:                       # lm_head + argmax ran inside the C step
+                self._g_next.copy_(eng.next_tokens)
             else:
                 self._g_next.copy_((x @ self.model.lm_head.weight.t()).float().argmax(-1))
             return
@@ -284,15 +325,21 @@ class ContinuousBatcher:
             sl = it.req.slot
             st[sl], st[B + sl], st[2 * B + sl] = it.tokens[0], it.start, it.start
         self._g_stage.copy_(self._h_stage, non_blocking=True)            # stream-ordered before the replay
-        if self._graph is None:
-            self._decode_static()                                   # warm-up (allocations, lazy init)
+        eng, key = self._engine_for(max(it.start for it in items) + 1)
+        graph = self._graph if key == 0 else self._long[key][1]
+        if graph is None:
+            self._decode_static(eng)                                # warm-up (allocations, lazy init): the step itself, idempotent
             torch.cuda.synchronize(self.dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._decode_static()
-            self._graph = g
-        self._graph.replay()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._decode_static(eng)
+            if key == 0:
+                self._graph = graph
+            else:
+                self._long[key][1] = graph
+        graph.replay()
         self.graph_steps += 1
+        self.long_steps += key != 0
         if not sync:
             return None
         self._h_next.copy_(self._g_next, non_blocking=True)
@@ -309,6 +356,8 @@ class ContinuousBatcher:
             return 1
         if len(items) != len(self.sched.running):
             return 1
+        if self._engine_for(max(it.start for it in items) + self.max_burst + 1)[1] != 0:
+            return 1                             # (bursts feed tokens back through the short-form engine's buffers only)
         n = min(it.req.max_new_tokens - len(it.req.out) for it in items)
         n = min(n, min(self.sched.max_len - it.start for it in items), self.max_burst)
         return max(1, n)
@@ -434,6 +483,16 @@ class ContinuousBatcher:
             return []
         self.steps += 1
         self.tokens_scheduled += sum(len(it.tokens) for it in items)
+        t0 = time.perf_counter()
+        try:
+            return self._run_items(items)
+        finally:
+            if all(len(it.tokens) == 1 for it in items):
+                self.time_decode += time.perf_counter() - t0
+            else:
+                self.time_mixed += time.perf_counter() - t0
+
+    def _run_items(self, items: List[Item]) -> List[Request]:
         if self.use_graph and all(len(it.tokens) == 1 for it in items):
             n = self._burst_len(items)
             if n <= 1:

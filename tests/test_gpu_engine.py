@@ -190,14 +190,20 @@ def test_fused_gemv_each_prologue(H, I):
           max_position_embeddings=512), 300, 6, dict(long_context_from=0)),
     # the same through the split-KV attention (4 splits of 128 positions: 3 hold data at 300 tokens)
     (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
-          max_position_embeddings=512), 300, 6, dict(long_context_from=64, attn_splits=4)),
+          max_position_embeddings=512), 300, 6, dict(long_context_from=64, attn_splits=4, long_attention="pair")),
+    # ... and through the key-block attention (round 6: rope / append launch + onebit_attention_decode_rows, 64 positions per split)
+    (dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+          max_position_embeddings=512), 300, 6, dict(long_context_from=64, long_attention="keyblock", attn_chunk=64)),
     # positions 55 .. 74: the first nine steps replay the graph whose attention requests 64 positions before it knows the
     # position (onebit_decode_state_t.attn_blind), the rest the 128-position graph -- the same logits on either side of 64
     (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
           max_position_embeddings=128), 55, 20, dict(long_context_from=0)),
     # split-KV with grouped-query attention and a position crossing a split boundary (chunk = 32)
     (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
-          num_key_value_heads=2, max_position_embeddings=256), 60, 10, dict(long_context_from=16, attn_splits=8)),
+          num_key_value_heads=2, max_position_embeddings=256), 60, 10, dict(long_context_from=16, attn_splits=8, long_attention="pair")),
+    # key-block form with grouped-query attention, positions 60 .. 69 crossing the 64-position split boundary
+    (dict(vocab_size=256, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+          num_key_value_heads=2, max_position_embeddings=256), 60, 10, dict(long_context_from=16, long_attention="keyblock", attn_chunk=64)),
 ])
 def test_engine_attention_variants(cfgkw, prompt_len, steps, engine_kw):
     from onebit_amd.engine import DecodeEngine
@@ -217,7 +223,8 @@ def test_engine_attention_variants(cfgkw, prompt_len, steps, engine_kw):
         tok = lg[:, -1].argmax(-1, keepdim=True)
         ref_toks.append(int(tok))
     eng = DecodeEngine(model, max_len=cfg.max_position_embeddings, **engine_kw)
-    assert (eng.graph_long is not None) == bool(engine_kw.get("long_context_from"))
+    assert (eng.graph_long is not None or bool(eng._kb_graphs)) == bool(engine_kw.get("long_context_from"))
+    assert bool(eng._kb_graphs) == (bool(engine_kw.get("long_context_from")) and engine_kw.get("long_attention") == "keyblock")
     assert eng.graph64 is not None and eng._state64.attn_blind == 64 and eng._state.attn_blind == 0
     eng.prefill(ids)
     assert eng.first_token == ref_toks[0]
@@ -241,9 +248,14 @@ def test_engine_is_deterministic_across_graphs_and_runs():
     ids = torch.randint(0, 512, (1, 40), generator=torch.Generator().manual_seed(1)).to(dev)
     runs = []
     for _ in range(2):
-        eng = DecodeEngine(model, max_len=320, long_context_from=96, attn_splits=4)
+        eng = DecodeEngine(model, max_len=320, long_context_from=96, attn_splits=4, long_attention="pair")
         runs.append(eng.generate(ids, 200)[0].tolist())
     assert runs[0] == runs[1]
+    kb = []
+    for _ in range(2):                           # the key-block form: fixed-order combine by the last arriver, tickets back at zero
+        eng = DecodeEngine(model, max_len=320, long_context_from=96, long_attention="keyblock", attn_chunk=64)
+        kb.append(eng.generate(ids, 200)[0].tolist())
+    assert kb[0] == kb[1]
     assert len(set(runs[0][40:])) > 8            # not a degenerate constant stream
 
 

@@ -263,3 +263,74 @@ def test_mixed_step_at_13b_widths_chunked_prompts_next_to_decoding_slots():
         ref = model.generate(torch.tensor([p], device=dev), m)[0, len(p):].tolist()
         assert len(out[rid]) == m
         assert out[rid] == ref or _near_tie(model, p, ref, out[rid], dev), rid
+
+
+@pytest.mark.parametrize("chunk,ctxs", [(64, [1, 5, 63, 64, 65, 130, 200]), (128, [7, 128, 129, 255, 256, 300, 2])])
+def test_batched_step_keyblock_attention_matches_the_one_workgroup_form(chunk, ctxs):
+    """onebit_decode_step_batched with attn_splits (LayerNorm + RoPE + append launch, then (head, slot, split) workgroups) against
+    the one-workgroup-per-(head, slot) attention on the same caches: contexts on both sides of the split boundaries, an idle slot;
+    logits within fp16 rounding of each other (the key-block form does not round the probabilities to fp16), equal greedy tokens."""
+    from onebit_amd.engine import BatchedDecodeStep
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device(DEV)
+    cfg = OneBitLlamaConfig(vocab_size=640, hidden_size=1024, intermediate_size=2816, num_hidden_layers=2,
+                            num_attention_heads=8, max_position_embeddings=320)
+    model = build_synthetic_model(cfg, seed=31, device=dev)
+    B, max_len = len(ctxs) + 1, 320
+    g = torch.Generator(device="cpu").manual_seed(chunk)
+    base = [(torch.randn(B, cfg.num_key_value_heads, max_len, cfg.head_dim, generator=g) * 0.5).half().to(dev) for _ in range(2 * cfg.num_hidden_layers)]
+    toks = torch.randint(0, cfg.vocab_size, (B,), generator=g).to(torch.int32)
+    pos = torch.tensor([c - 1 for c in ctxs] + [-1], dtype=torch.int32)
+    res = []
+    for splits in (0, -(-max_len // chunk)):
+        caches = [(base[2 * l].clone(), base[2 * l + 1].clone()) for l in range(cfg.num_hidden_layers)]
+        st = BatchedDecodeStep(model, caches, B, max_len, keep_logits=True, attn_splits=splits, attn_chunk=chunk)
+        st.tokens.copy_(toks)
+        st.pos.copy_(pos)
+        st.launch()
+        torch.cuda.synchronize()
+        res.append((st.logits.float().clone(), st.next_tokens.clone(), caches))
+    (l0, t0, c0), (l1, t1, c1) = res
+    live = slice(0, B - 1)
+    scale = float(l0[live].abs().max())
+    assert float((l0[live] - l1[live]).abs().max()) < 4e-3 * scale
+    assert torch.equal(t0[live], t1[live])
+    # the appended keys / values: the same arithmetic; the short form takes its LayerNorm statistics from the GEMM's tile partials,
+    # the rope kernel reduces the rows itself -- mean / rstd differ in the last fp32 bit, the rows by an fp16 ulp here and there
+    for (k0, v0), (k1, v1) in zip(c0, c1):
+        assert float((k0.float() - k1.float()).abs().max()) <= 2.0 ** -9 * float(k0.abs().max())
+        assert float((v0.float() - v1.float()).abs().max()) <= 2.0 ** -9 * float(v0.abs().max())
+        assert float((k0 != k1).float().mean()) < 0.02
+
+
+def test_engines_take_the_keyblock_graphs_at_long_contexts():
+    """DecodeEngine (long_context_from = 8: one graph per power-of-two split count) and ContinuousBatcher (long_context_from = 8)
+    on a small synthetic model: tokens equal the module path's generate."""
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.serving import ContinuousBatcher
+    dev = torch.device(DEV)
+    cfg = OneBitLlamaConfig(vocab_size=160, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                            max_position_embeddings=256)
+    model = build_synthetic_model(cfg, seed=77, device=dev)
+    V = model.config.vocab_size
+    g = torch.Generator().manual_seed(23)
+    p = torch.randint(0, V, (1, 5), generator=g).to(dev)
+    ref = model.generate(p, 150)
+    for la in ("keyblock", "pair"):
+        eng = DecodeEngine(model, max_len=200, long_context_from=8, long_attention=la, attn_chunk=64)
+        assert eng._keyblock == (la == "keyblock")
+        out = eng.generate(p, 150)
+        if not torch.equal(out, ref):
+            j = int((out[0] != ref[0]).nonzero()[0])
+            assert _near_tie(model, ref[0, :5].tolist(), ref[0, 5:].tolist(), out[0, 5:].tolist(), dev), (la, j)
+        if la == "keyblock":
+            assert sorted(eng._kb_graphs) == [1, 2, 4]
+    reqs = [(torch.randint(0, V, (n,), generator=g).tolist(), m) for n, m in [(6, 90), (30, 70), (2, 110), (70, 30), (11, 60)]]
+    cb = ContinuousBatcher(model, max_batch=3, max_len=160, long_context_from=8, attn_chunk=64)
+    rids = [cb.add_request(pp, m) for pp, m in reqs]
+    out = cb.run()
+    assert cb.long_steps > 0 and len(cb._long) >= 2
+    for rid, (pp, m) in zip(rids, reqs):
+        r = model.generate(torch.tensor([pp], device=dev), m)[0, len(pp):].tolist()
+        assert out[rid] == r or _near_tie(model, pp, r, out[rid], dev), rid

@@ -6,7 +6,8 @@ from onebit_amd.engine import DecodeEngine
 dev = torch.device("cuda:0")
 cfg = OneBitLlamaConfig.llama_7b()
 model = build_synthetic_model(cfg, seed=1, device=dev)
-eng = DecodeEngine(model, max_len=2048, attn_splits=int(os.environ.get("SPLITS", "8")), long_context_from=int(os.environ.get("LONG_FROM", "384")))
+eng = DecodeEngine(model, max_len=2048, attn_splits=int(os.environ.get("SPLITS", "8")), long_context_from=int(os.environ.get("LONG_FROM", "384")),
+                   long_attention=os.environ.get("LONG_ATTN", "keyblock"), attn_chunk=int(os.environ.get("CHUNK", "128")))
 for kc, vc in eng.cache.layers:                       # plausible cache contents
     kc.normal_(); vc.normal_()
 for ctx in (16, 128, 256, 512, 1024, 1900):
