@@ -32,6 +32,7 @@ import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -81,6 +82,10 @@ def parse(argv=None):
     ap.add_argument("--no-k-sharded-decode", action="store_true",
                     help="skip BASELINE config 4 (LLaMA-13B shapes, module-path decode with every 1-bit layer K-sharded "
                          "over the ranks, one all-reduce per BitLinearInf call; extra JSON field, not the headline value)")
+    ap.add_argument("--deadline", type=float, default=1500.0,
+                    help="seconds after the headline measurement at which rank 0 prints the JSON line with whatever legs have finished "
+                         "(field `incomplete`) and every rank exits: a hung secondary leg (a collective that never returns) cannot suppress the line")
+    ap.add_argument("--pg-timeout", type=float, default=120.0, help="process-group timeout in seconds (N > 1)")
     return ap.parse_args(argv)
 
 
@@ -359,21 +364,49 @@ def measure_k_sharded_decode(cfg, dev, world, rank, steps, prompt_len):
         del eng
     except Exception as e:
         out["single_gpu_engine"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    try:    # round 5: native segments (onebit_decode_step_ksharded), q|k|v and gate|up one exchange each, ONE HIP graph
+    def agree(ok):
+        """True only if `ok` on EVERY rank: a rank that failed a phase must not leave the others alone in the next collective."""
+        if world <= 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    # round 5: native segments (onebit_decode_step_ksharded), q|k|v and gate|up one exchange each.  Round 6: the EAGER (uncaptured)
+    # run first -- its number stands if capturing the collectives into a HIP graph fails on any rank (agreed by an all-reduce of a
+    # flag before anybody replays)
+    fdec, err = None, None
+    try:
         from onebit_amd.sharded import FusedKShardedDecoder
-        fdec = FusedKShardedDecoder(model, rank, world, max_len=max_len, use_graph=True)
-        fdec.prime(prompt)
-        dt = timed(fdec.step, 3)
-        L = cfg.num_hidden_layers
-        out["fused"] = {"ms_per_token": round(dt / steps * 1e3, 4), "tokens_per_s": round(steps / dt, 1),
-                        "path": "FusedKShardedDecoder: onebit_decode_step_ksharded segments (decode GEMV in fp32-partial form on the rank's "
-                                "K slice, row kernels, decode attention) + all_reduce(fp32) replayed as one HIP graph",
-                        "collectives_per_token": fdec.collectives_per_token, "launches_per_token": 8 * L + 3,
-                        "reduced_fp32_bytes_per_token": 4 * L * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim
-                                                                 + 2 * cfg.hidden_size + 2 * cfg.intermediate_size) if world > 1 else 0}
-        del fdec
+        fdec = FusedKShardedDecoder(model, rank, world, max_len=max_len, use_graph=False)
+        fdec.prime(prompt)                                         # (replicated module path: no collective inside)
     except Exception as e:
-        out["fused"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        err = "%s: %s" % (type(e).__name__, e)
+    if not agree(err is None):
+        out["fused"] = {"error": err or "another rank failed to build the fused decoder"}
+    else:
+        try:
+            L = cfg.num_hidden_layers
+            dt = timed(fdec.step, 3)
+            fused = {"ms_per_token": round(dt / steps * 1e3, 4), "tokens_per_s": round(steps / dt, 1),
+                     "path": "FusedKShardedDecoder, eager: onebit_decode_step_ksharded segments + all_reduce(fp32), host-issued",
+                     "collectives_per_token": fdec.collectives_per_token, "launches_per_token": 8 * L + 3,
+                     "reduced_fp32_bytes_per_token": 4 * L * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim
+                                                              + 2 * cfg.hidden_size + 2 * cfg.intermediate_size) if world > 1 else 0}
+            out["fused_eager"] = dict(fused)
+            fdec.use_graph = True
+            if agree(fdec.capture()):
+                dt = timed(fdec.step, 3)
+                fused.update(ms_per_token=round(dt / steps * 1e3, 4), tokens_per_s=round(steps / dt, 1),
+                             path="FusedKShardedDecoder: onebit_decode_step_ksharded segments (decode GEMV in fp32-partial form on the rank's "
+                                  "K slice, row kernels, decode attention) + all_reduce(fp32) replayed as one HIP graph")
+            else:
+                fdec.use_graph, fdec.graph = False, None
+                fused["graph_capture"] = "failed on at least one rank: the eager figure stands"
+            out["fused"] = fused
+        except Exception as e:
+            out["fused"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    del fdec
     torch.cuda.empty_cache()
     shard_model_k(model, rank, world, mode="allreduce")
     torch.cuda.empty_cache()
@@ -496,6 +529,79 @@ def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, i
     return {"step": step, "request_stream": stream, "per": "GPU", "data": "synthetic"}
 
 
+def measure_decode_ctx(model, dev, contexts=(512, 2000), slots=32, slot_ctx=512, steps=32):
+    """Decode against LONG contexts (the headline runs at <= 42 cached tokens): single stream through DecodeEngine at `contexts`
+    cached tokens (key-block attention graphs: onebit_rows_qkv_rope_ragged + onebit_attention_decode_rows), and the `slots`-slot
+    batched step at `slot_ctx` cached tokens per slot in both attention forms.  KV rate = the K / V bytes of the context over the
+    time the step takes BEYOND the same step at 16 cached tokens (what streaming the context costs)."""
+    from onebit_amd.engine import BatchedDecodeStep, DecodeEngine
+    cfg = model.config
+    H, D, L = cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
+    max_len = min(cfg.max_position_embeddings, max(max(contexts), slot_ctx) + steps + 16)
+    eng = DecodeEngine(model, max_len=max_len)
+    for kc, vc in eng.cache.layers:
+        kc.normal_(); vc.normal_()
+
+    def single(ctx):
+        eng.set_state(5, ctx)
+        for _ in range(4):
+            eng.step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+    base = single(16)
+    one = {"cached_tokens_16": {"ms_per_token": round(base * 1e3, 4)}}
+    for ctx in contexts:
+        ctx = min(ctx, max_len - steps - 8)
+        t = single(ctx)
+        kv = L * cfg.num_key_value_heads * (ctx + steps // 2) * D * 2 * 2
+        one["cached_tokens_%d" % ctx] = {"ms_per_token": round(t * 1e3, 4), "tokens_per_s": round(1.0 / t, 1), "kv_bytes_per_token": kv,
+                                        "kv_GBps_over_the_short_step": round(kv / max(t - base, 1e-9) / 1e9, 1),
+                                        "frac_of_8TBps": round(kv / max(t - base, 1e-9) / 1e9 / HBM_PEAK_GBS, 3)}
+    one["attention"] = "key-block: rope / append launch + onebit_attention_decode_rows (%d positions per workgroup), one HIP graph per split count" % eng._kb_chunk \
+        if eng._keyblock else "scores + P.V kernel pair"
+    del eng
+    torch.cuda.empty_cache()
+    caches = model.new_cache(slots, max_len).layers
+    for kc, vc in caches:
+        kc.normal_(); vc.normal_()
+
+    def batched(step, ctx):
+        step.tokens.fill_(5)
+        step.pos.fill_(ctx - 1)
+        step.launch()
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step.launch()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / steps
+    ns = max(1, -(-slot_ctx // 512))
+    short = BatchedDecodeStep(model, caches, slots, max_len)
+    kb = BatchedDecodeStep(model, caches, slots, max_len, attn_splits=ns, attn_chunk=512)
+    b16 = batched(short, 16)
+    t_short, t_kb = batched(short, slot_ctx), batched(kb, slot_ctx)
+    kvb = slots * L * cfg.num_key_value_heads * slot_ctx * D * 2 * 2
+    bat = {"slots": slots, "cached_tokens_per_slot": slot_ctx, "kv_bytes_per_step": kvb, "ms_per_step_at_16_cached": round(b16, 3),
+           "one_workgroup_per_head_slot": {"ms_per_step": round(t_short, 3), "kv_GBps_over_the_short_step": round(kvb / max(t_short - b16, 1e-9) / 1e6, 1)},
+           "key_block": {"ms_per_step": round(t_kb, 3), "splits": ns, "chunk": 512,
+                         "kv_GBps_over_the_short_step": round(kvb / max(t_kb - b16, 1e-9) / 1e6, 1),
+                         "frac_of_8TBps": round(kvb / max(t_kb - b16, 1e-9) / 1e6 / HBM_PEAK_GBS, 3)},
+           "tokens_per_s": round(slots / min(t_short, t_kb) * 1e3, 1)}
+    return {"single_stream": one, "batched": bat, "per": "GPU", "data": "synthetic (random K / V rows)"}
+
+
 def measure_prefill_model(model, dev, B=8, S=2048):
     """BASELINE configs[2]: whole-model prefill of B x S tokens (1-bit GEMMs + fused row glue +
     the vendor's fused attention), tokens/s and the 1-bit layers' share expressed in TFLOP/s."""
@@ -604,7 +710,7 @@ def measure_eval(model, dev, windows=8, seqlen=2048, requests=32):
                                      "ms": round(dt_l * 1e3, 1), "tokens_per_s_padded": round(requests * pad_to / dt_l, 1),
                                      "tokens_per_s_real": round(sum(len(c) + len(t) - 1 for c, t in reqs) / dt_l, 1),
                                      "gemm_routes": routes(requests * pad_to), "finite": bool(all(v[0] == v[0] for v in res)),
-                                     "includes": "log_softmax over the vocabulary and the device->host copy of the [B, S, vocab] log-probabilities, as the reference does (models_utils.py:331)"},
+                                     "includes": "log_softmax over the continuation rows, gather + greedy flags on the device, sum(contlen) floats to the host (round 6; the reference ships [B, S, vocab] log-probabilities to the host, models_utils.py:331)"},
             "route": "set_fused_glue + onebit_attention_prefill (the config-3 prefill route)", "per": "GPU", "data": "synthetic"}
 
 
@@ -724,6 +830,44 @@ def measure_train_layer(dev, T=4096, K=4096, N=11008, iters=5):
             "per": "GPU", "data": "synthetic"}
 
 
+class Emitter:
+    """The one JSON line, printed exactly once: by main() when every leg is done, or by the deadline timer with the legs finished
+    so far (`incomplete` names the rest) -- after which every rank leaves with os._exit, whatever its main thread is stuck in."""
+
+    def __init__(self, rank, deadline_s):
+        self.rank, self.out, self.done, self.pending = rank, None, False, []
+        self.lock = threading.Lock()
+        self.timer = threading.Timer(deadline_s, self._fire)
+        self.timer.daemon = True
+        self.deadline_s = deadline_s
+
+    def arm(self, out):
+        self.out = out
+        self.timer.start()
+
+    def emit(self, reason=None):
+        with self.lock:
+            if self.done or self.out is None:
+                return False
+            self.done = True
+            if reason:
+                self.out["incomplete"] = {"reason": reason, "legs_not_finished": list(self.pending)}
+            sys.stdout.flush()
+            print(json.dumps(self.out), flush=True)       # the one JSON line, last on stdout
+            return True
+
+    def _fire(self):
+        if self.rank == 0:
+            self.emit("deadline of %.0f s after the headline measurement reached with a secondary leg still running" % self.deadline_s)
+        else:
+            time.sleep(2.0)                               # (rank 0 prints first)
+        sys.stdout.flush()
+        os._exit(0)
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 class Hooks:
     """Everything main() touches besides its own control flow (which ranks run what, where the collectives and
     barriers sit, how the JSON line is assembled).  The world-2 gloo test (tests/test_bench_cpu.py) substitutes CPU
@@ -735,9 +879,13 @@ class Hooks:
         torch.cuda.set_device(dev)
         return dev
 
-    def init_process_group(self, dev):
+    def init_process_group(self, dev, timeout_s=120.0):
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group(self.backend, device_id=dev)
+        # a collective that does not complete within the timeout must not take the process (and the JSON line) with it: the
+        # watchdog's abort is switched off, the hung leg is ended by bench.py's own deadline (Emitter below)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        dist.init_process_group(self.backend, device_id=dev, timeout=datetime.timedelta(seconds=timeout_s))
 
     def sync(self, dev):
         torch.cuda.synchronize(dev)
@@ -761,6 +909,7 @@ class Hooks:
     measure_prefill_sharded = staticmethod(measure_prefill_sharded)
     measure_continuous_batch = staticmethod(measure_continuous_batch)
     measure_mixed_step = staticmethod(measure_mixed_step)
+    measure_decode_ctx = staticmethod(measure_decode_ctx)
     measure_prefill_model = staticmethod(measure_prefill_model)
     measure_prefill_model_tp = staticmethod(measure_prefill_model_tp)
     measure_k_sharded_decode = staticmethod(measure_k_sharded_decode)
@@ -786,7 +935,7 @@ def main(argv=None, hooks=None):
     dev = hk.device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        hk.init_process_group(dev)
+        hk.init_process_group(dev, args.pg_timeout)
         rccl_ranks = dist.get_world_size()
         assert rccl_ranks == args.gpus, (rccl_ranks, args.gpus)
 
@@ -839,83 +988,9 @@ def main(argv=None, hooks=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    roof = None
-    if rank == 0 and not args.no_roofline:      # right after the decode phase: same thermal / clock state as the headline
-        ctx0 = args.prompt + args.warmup + args.steps // 2
-        roof = hk.measure_roofline(model, dev, dt / args.steps * 1e3, token_bytes(cfg, ctx0)[1])
-    prefill = None
-    if not args.no_prefill:
-        try:
-            prefill = hk.measure_prefill_sharded(cfg, dev, world, rank)
-        except Exception as e:              # the decode line must survive a failure of the secondary measurement
-            prefill = {"error": "%s: %s" % (type(e).__name__, e)}
-    serve = None
-    if not args.no_serve and rank == 0:
-        try:
-            serve = hk.measure_continuous_batch(model, dev)
-        except Exception as e:
-            serve = {"error": "%s: %s" % (type(e).__name__, e)}
-    pmodel = None
-    if not args.no_prefill and rank == 0:
-        try:
-            pmodel = hk.measure_prefill_model(model, dev)
-        except Exception as e:
-            pmodel = {"error": "%s: %s" % (type(e).__name__, e)}
-    evalf = None
-    if not args.no_eval and rank == 0:          # the evaluation callers at their real shape
-        try:
-            evalf = hk.measure_eval(model, dev)
-        except Exception as e:
-            evalf = {"error": "%s: %s" % (type(e).__name__, e)}
-    trainf = None
-    if not args.no_train and rank == 0:         # the train-mode layer
-        try:
-            trainf = hk.measure_train_layer(dev)
-        except Exception as e:
-            trainf = {"error": "%s: %s" % (type(e).__name__, e)}
-    pmodel_tp = None
-    if not args.no_prefill:
-        try:
-            if world > 1:                       # the same checkpoint on every rank (the decode replicas were seeded per rank)
-                del model
-                hk.empty_cache()
-                model = hk.build_model(cfg, 4242, dev)
-            pmodel_tp = hk.measure_prefill_model_tp(model, dev, world, rank)
-        except Exception as e:
-            pmodel_tp = {"error": "%s: %s" % (type(e).__name__, e)}
-    ksd = None
-    if not args.no_k_sharded_decode:            # BASELINE config 4 on LLaMA-13B shapes at every N (N = 1: the line the N > 1 ones compare with)
-        try:
-            del stepper
-            model = None
-            hk.empty_cache()
-            ksd = hk.measure_k_sharded_decode(model_config("13b"), dev, world, rank, min(args.steps, 16), args.prompt)
-            ksd["model"] = "LLaMA-13B shapes"
-        except Exception as e:
-            ksd = {"error": "%s: %s" % (type(e).__name__, e)}
-    if serve is not None and "error" not in serve and rank == 0 and args.model == "7b":
-        # BASELINE config 5 names LLaMA2-13B: the same 32-slot steady-state step on a 13B-shaped synthetic checkpoint
-        try:
-            stepper = model = None
-            hk.empty_cache()
-            m13 = hk.build_model(model_config("13b"), 4242, dev)
-            serve["llama2_13b_shapes"] = hk.measure_continuous_batch(m13, dev)
-            try:                                # config 5's defining workload: prompt chunks next to decoding requests, native step
-                serve["mixed"] = hk.measure_mixed_step(m13, dev)
-                serve["mixed"]["model"] = "LLaMA2-13B shapes"
-            except Exception as e:
-                serve["mixed"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            del m13
-            hk.empty_cache()
-        except Exception as e:
-            serve["llama2_13b_shapes"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    cpu = None
-    if rank == 0:
-        if not args.no_cpu_baseline:            # at every N (rank 0's host cores; the other ranks wait at the barrier below)
-            cpu = hk.measure_cpu_baseline(cfg)
-    if world > 1:
-        dist.barrier()
-
+    # ---- the headline line exists from here on; every further leg only ADDS a field to it ----
+    em = Emitter(rank, args.deadline)
+    out = None
     if rank == 0:
         ctx = args.prompt + args.warmup + args.steps // 2
         star_b, tok_b = token_bytes(cfg, ctx)
@@ -934,25 +1009,93 @@ def main(argv=None, hooks=None):
             "token_hbm": {"algorithmic_bytes_per_token": tok_b, "onebit_layer_bytes_per_token": star_b,
                           "achieved_GBps_whole_token": round(tok_b * per_gpu_tok_s / 1e9, 1),
                           "frac_of_8TBps": round(tok_b * per_gpu_tok_s / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline": roof, "cpu_baseline": cpu, "prefill_k_sharded": prefill,
+            "roofline": None, "cpu_baseline": None, "prefill_k_sharded": None,
         }
-        if ksd is not None:
-            out["decode_k_sharded"] = ksd
-        if serve is not None:
-            out["continuous_batch"] = serve
-        if pmodel is not None:
-            out["prefill_model"] = pmodel
-        if pmodel_tp is not None:
-            out["prefill_model_tp"] = pmodel_tp
-        if evalf is not None:
-            out["eval_ppl"] = evalf
-        if trainf is not None:
-            out["train_layer"] = trainf
+    em.arm(out)
+
+    def leg(name, fn, where="rank0", into=None, key=None):
+        """Run one secondary measurement: an exception becomes {"error": ...}, a hang is ended by the Emitter's deadline; the result
+        goes to out[name] (or into[key]) on rank 0.  `where`: "rank0" (the other ranks skip it) or "all" (every rank enters)."""
+        if where == "rank0" and rank != 0:
+            return None
+        em.pending.append(name)
+        try:
+            res = fn()
+        except Exception as e:              # the decode line must survive a failure of a secondary measurement
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0 and res is not None:
+            (out if into is None else into)[name if key is None else key] = res
+        em.pending.remove(name)
+        return res
+
+    if not args.no_roofline:                    # right after the decode phase: same thermal / clock state as the headline
+        ctx0 = args.prompt + args.warmup + args.steps // 2
+        leg("roofline", lambda: hk.measure_roofline(model, dev, dt / args.steps * 1e3, token_bytes(cfg, ctx0)[1]))
+    if not args.no_prefill:
+        leg("prefill_k_sharded", lambda: hk.measure_prefill_sharded(cfg, dev, world, rank), where="all")
+    serve = None
+    if not args.no_serve:
+        serve = leg("continuous_batch", lambda: hk.measure_continuous_batch(model, dev))
+    if not args.no_prefill:
+        leg("prefill_model", lambda: hk.measure_prefill_model(model, dev))
+    if not args.no_eval:                        # the evaluation callers at their real shape (SURVEY.md 8 f3)
+        leg("eval_ppl", lambda: hk.measure_eval(model, dev))
+    if not args.no_train:                       # the train-mode layer (SURVEY.md 8 a8 / f4)
+        leg("train_layer", lambda: hk.measure_train_layer(dev))
+    if not args.no_serve and hasattr(hk, "measure_decode_ctx"):      # long-context decode (single stream and 32 slots)
+        leg("decode_ctx", lambda: hk.measure_decode_ctx(model, dev))
+    if not args.no_prefill:
+        def tp_leg():
+            nonlocal model
+            if world > 1:                       # the same checkpoint on every rank (the decode replicas were seeded per rank)
+                model = None
+                hk.empty_cache()
+                model = hk.build_model(cfg, 4242, dev)
+            return hk.measure_prefill_model_tp(model, dev, world, rank)
+        leg("prefill_model_tp", tp_leg, where="all")
+    if not args.no_k_sharded_decode:            # BASELINE config 4 on LLaMA-13B shapes at every N (N = 1: the line the N > 1 ones compare with)
+        def ksd_leg():
+            nonlocal model, stepper
+            stepper = model = None
+            hk.empty_cache()
+            res = hk.measure_k_sharded_decode(model_config("13b"), dev, world, rank, min(args.steps, 16), args.prompt)
+            res["model"] = "LLaMA-13B shapes"
+            return res
+        leg("decode_k_sharded", ksd_leg, where="all")
+    if serve is not None and "error" not in serve and rank == 0 and args.model == "7b":
+        # BASELINE config 5 names LLaMA2-13B: the 32-slot steady-state step and the mixed prefill + decode workload on a 13B-shaped checkpoint
+        m13 = {}
+
+        def build13():
+            nonlocal model, stepper
+            stepper = model = None
+            hk.empty_cache()
+            m13["m"] = hk.build_model(model_config("13b"), 4242, dev)
+            return hk.measure_continuous_batch(m13["m"], dev)
+        leg("continuous_batch.llama2_13b_shapes", build13, into=serve, key="llama2_13b_shapes")
+        if "m" in m13:
+            def mixed13():
+                res = hk.measure_mixed_step(m13["m"], dev)
+                res["model"] = "LLaMA2-13B shapes"
+                return res
+            leg("continuous_batch.mixed", mixed13, into=serve, key="mixed")
+        m13.clear()
+        hk.empty_cache()
+    if not args.no_cpu_baseline:                # at every N (rank 0's host cores; the other ranks wait at the barrier below)
+        leg("cpu_baseline", lambda: hk.measure_cpu_baseline(cfg))
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+    em.cancel()
     if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)       # the one JSON line, last on stdout
+        em.emit()                               # BEFORE the process group is torn down: a stuck communicator cannot eat the line
+    if world > 1:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -119,15 +119,25 @@ def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence
             inplens.append(inplen)
             conts.append(cont)
         batched = torch.cat(inps, dim=0).to(dev)
-        multi_logits = F.log_softmax(_model_logits(model, batched), dim=-1).cpu()
-        for key, logits, inplen, cont in zip(chunk, multi_logits, inplens, conts):
+        logits = _model_logits(model, batched)                                  # [B, S, vocab] on the device
+        # Score ON THE DEVICE (round 6).  The reference ships log_softmax of the whole [B, S, vocab] tensor to the host
+        # (models_utils.py:331-334: 1.6 GB for a 32 x 389 batch of a 32000-word vocabulary) to read sum(contlen) numbers from it.
+        # log_softmax is row-wise, so it is taken over the continuation rows [inplen - contlen, inplen) only -- the same values --,
+        # the continuation's log-probabilities are gathered and the greedy flags formed there; the host receives sum(contlen)
+        # floats + flags and adds each request's log-probabilities in the reference's order (fp32 on the CPU, :352).
+        b_idx = torch.tensor([b for b, (n, c) in enumerate(zip(inplens, conts)) for _ in c], dtype=torch.long, device=dev)
+        p_idx = torch.tensor([n - len(c) + j for n, c in zip(inplens, conts) for j in range(len(c))], dtype=torch.long, device=dev)
+        cont_t = torch.tensor([t for c in conts for t in c], dtype=torch.long, device=dev)
+        lsm = F.log_softmax(logits[b_idx, p_idx], dim=-1)                        # [sum(contlen), vocab]
+        if vocab_size is not None:
+            lsm = lsm[:, :vocab_size]
+        greedy_tok = (lsm.argmax(dim=-1) == cont_t).cpu()
+        lp_all = torch.gather(lsm, 1, cont_t.unsqueeze(-1)).squeeze(-1).cpu()
+        o = 0
+        for key, cont in zip(chunk, conts):
             contlen = len(cont)
-            lg = logits[inplen - contlen:inplen]
-            if vocab_size is not None:
-                lg = lg[:, :vocab_size]
-            cont_t = torch.tensor(cont, dtype=torch.long)
-            is_greedy = bool((lg.argmax(dim=-1) == cont_t).all())
-            lp = torch.gather(lg, 1, cont_t.unsqueeze(-1)).squeeze(-1)
+            lp, is_greedy = lp_all[o:o + contlen], bool(greedy_tok[o:o + contlen].all())
+            o += contlen
             for i in groups[key]:
                 res[i] = (float(lp.sum()), is_greedy)
     if world > 1:

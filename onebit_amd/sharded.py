@@ -622,26 +622,43 @@ class FusedKShardedDecoder:
         self.token.fill_(int(token)); self.pos.fill_(int(pos)); self.steps = int(pos)
 
     @torch.no_grad()
+    def capture(self) -> bool:
+        """Warm-up + capture of one step (kernels AND collectives) into a HIP graph.  Returns False -- the decoder then keeps
+        stepping eagerly -- if the capture raised: with world > 1 the CALLER must agree on the outcome across ranks before anybody
+        replays (an all-reduce of the flag: bench.py), or one rank replays collectives the others issue eagerly."""
+        if self.graph is not None:
+            return True
+        tok0, pos0 = self.token.clone(), self.pos.clone()
+        try:
+            side = torch.cuda.Stream(self.dev)           # warm-up off the capture: function attributes, communicators
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._step()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            self.token.copy_(tok0); self.pos.copy_(pos0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step()
+            self.graph = g
+            return True
+        except Exception as e:                            # (a failed capture leaves the stream usable: torch ends it on the way out)
+            self.capture_error = "%s: %s" % (type(e).__name__, e)
+            self.graph = None
+            self.use_graph = False
+            return False
+        finally:
+            self.token.copy_(tok0); self.pos.copy_(pos0)
+
+    @torch.no_grad()
     def step(self):
         if self.steps >= self.max_len:
             raise RuntimeError("FusedKShardedDecoder: KV cache full")
-        if not self.use_graph:
-            self._step()
-        else:
-            if self.graph is None:
-                tok0, pos0 = self.token.clone(), self.pos.clone()
-                side = torch.cuda.Stream(self.dev)           # warm-up off the capture: function attributes, communicators
-                side.wait_stream(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(side):
-                    self._step()
-                torch.cuda.current_stream(self.dev).wait_stream(side)
-                self.token.copy_(tok0); self.pos.copy_(pos0)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._step()
-                self.token.copy_(tok0); self.pos.copy_(pos0)
-                self.graph = g
+        if self.use_graph and self.graph is None:
+            self.capture()
+        if self.use_graph and self.graph is not None:
             self.graph.replay()
+        else:
+            self._step()
         self.steps += 1
 
     def logits(self) -> torch.Tensor:

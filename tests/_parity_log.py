@@ -1,7 +1,19 @@
-"""Model-level parity bookkeeping (round-4 review, weak #1): every route's measured max |delta logit| against the reference's
-fp16 AND fp32 goldens is written to gpurun_out/r05_model_parity.txt (copied to profiles/) when OB_WRITE_PROFILES=1, and the
-tests' bar is 1.25 x the worst error OBSERVED for that golden (``OBSERVED``, from profiles/r05_model_parity.txt), never
-looser than the round-1..4 bar max(2 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)."""
+"""Model-level parity bookkeeping: every route's measured max |delta logit| against the reference's fp16 AND fp32 goldens is
+written to gpurun_out/r06_model_parity.txt (copied to profiles/) when OB_WRITE_PROFILES=1.
+
+The BAR is derived from the golden itself, not from this implementation's own output (round-5 review, weak #1 / advisor):
+
+    bar = max(GAP_FACTOR x gap, 2e-3 x logit scale),   gap = max |reference fp16 logits - reference fp32 logits|
+
+``gap`` is what the reference's OWN fp16 arithmetic costs on this input: the maximum over the logits of one realisation of fp16
+rounding noise through the same network.  A correct fp16 implementation with a different (equally valid) summation order is
+another, independent realisation of that noise: its distance to the fp32 golden is distributed like ``gap`` itself, its distance
+to the fp16 golden like the difference of two independent realisations, i.e. sqrt(2) x as wide.  GAP_FACTOR = 1.6 = sqrt(2) x
+1.13: the sqrt(2) of that difference plus 13 % for the spread of a maximum over 10^4 - 10^6 logits from box to box (the module
+path's torch GEMMs are not bit-reproducible across boxes).  Measured ratios error / gap over rounds 4-6, all routes, 8 boxes:
+0.70 ... 1.30 (``OBSERVED`` below) -- inside the bar with >= 23 % to spare, while a real defect (a dropped rounding point, a
+wrong LayerNorm statistic) moves the error by integer multiples of the gap.  ``OBSERVED`` is kept as a LOGGED regression
+indicator (the profile line says how the run compares with it); it is no longer asserted."""
 import os
 
 import numpy as np
@@ -31,8 +43,11 @@ OBSERVED = {
 }
 
 
+GAP_FACTOR = 1.6
+
+
 def loose_tol(ref16, ref32):
-    return max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
+    return max(GAP_FACTOR * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
 
 
 def check(fixture, name, route, got, ref16, ref32, loose=None):
@@ -42,15 +57,16 @@ def check(fixture, name, route, got, ref16, ref32, loose=None):
     got = got.astype(np.float32)
     e16, e32 = float(np.abs(got - ref16).max()), float(np.abs(got - ref32).max())
     gap, scale = float(np.abs(ref16 - ref32).max()), float(np.abs(ref32).max())
-    loose = loose_tol(ref16, ref32) if loose is None else loose        # (callers that compare a slice pass the whole golden's bar)
+    bar = loose_tol(ref16, ref32) if loose is None else loose          # (callers that compare a slice pass the whole golden's bar)
     obs = OBSERVED.get((fixture, name))
-    t16 = min(loose, 1.25 * obs[0]) if obs else loose
-    t32 = min(loose, 1.25 * obs[1]) if obs else loose
     if os.environ.get("OB_WRITE_PROFILES") == "1":
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "r05_model_parity.txt"), "a") as f:
-            f.write(f"{fixture:<18s} {name:<16s} {route:<34s} vs ref fp16 {e16:.5f}  vs ref fp32 {e32:.5f}  | reference's own fp16-fp32 gap {gap:.5f}  "
-                    f"logit scale {scale:.3f}  bar {t16:.5f} / {t32:.5f} (round-4 bar {loose:.5f})\n")
-    assert e16 <= t16, (fixture, name, route, "fp16 golden", e16, t16)
-    assert e32 <= t32, (fixture, name, route, "fp32 golden", e32, t32)
+        note = ""
+        if obs:
+            note = "  | worst of rounds 4-5: %.5f / %.5f%s" % (obs[0], obs[1], "  ABOVE IT" if e16 > obs[0] or e32 > obs[1] else "")
+        with open(os.path.join(ROOT, "gpurun_out", "r06_model_parity.txt"), "a") as f:
+            f.write(f"{fixture:<18s} {name:<16s} {route:<34s} vs ref fp16 {e16:.5f} ({e16 / max(gap, 1e-12):.2f} x gap)  vs ref fp32 {e32:.5f} "
+                    f"({e32 / max(gap, 1e-12):.2f} x gap)  | reference's own fp16-fp32 gap {gap:.5f}  logit scale {scale:.3f}  bar {bar:.5f}{note}\n")
+    assert e16 <= bar, (fixture, name, route, "fp16 golden", e16, bar)
+    assert e32 <= bar, (fixture, name, route, "fp32 golden", e32, bar)
     return e16, e32

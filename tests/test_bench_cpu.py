@@ -53,7 +53,7 @@ def test_csrc_sha_is_stable():
 
 
 # ---- bench.main() end to end with TWO ranks (gloo, CPU stand-ins for the device work) ----------------------------------
-def _main_worker(rank, world, port, q):
+def _main_worker(rank, world, port, q, fault=None, out_path=None):
     import contextlib
     import io
     import json
@@ -88,8 +88,9 @@ def _main_worker(rank, world, port, q):
         def device(self, local_rank):
             return torch.device("cpu")
 
-        def init_process_group(self, dev):
-            dist.init_process_group("gloo")
+        def init_process_group(self, dev, timeout_s=120.0):
+            import datetime
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
 
         def sync(self, dev):
             pass
@@ -126,7 +127,14 @@ def _main_worker(rank, world, port, q):
         @staticmethod
         def measure_prefill_model(model, dev):
             assert dist.get_rank() == 0
+            if fault == "raise":                                 # an injected failure of a secondary leg: recorded, nothing else lost
+                raise RuntimeError("injected failure")
             return {"ms": 1.0}
+
+        @staticmethod
+        def measure_decode_ctx(model, dev):
+            assert dist.get_rank() == 0
+            return {"single_stream": {}}
 
         @staticmethod
         def measure_eval(model, dev):
@@ -145,6 +153,9 @@ def _main_worker(rank, world, port, q):
 
         @staticmethod
         def measure_k_sharded_decode(cfg, dev, world_, rank_, steps, prompt):
+            if fault == "hang" and rank_ == 1:                   # one rank never arrives: rank 0 is stuck in the collective below
+                import time
+                time.sleep(3600)
             collective("k_sharded_decode")
             assert cfg.hidden_size == 5120                      # config 4 runs on 13B shapes at every N
             return {"k_shards": world_}
@@ -155,9 +166,18 @@ def _main_worker(rank, world, port, q):
             return {"value": 1.0, "unit": "tokens/s", "cores": 1, "kind": "port", "sample": "stand-in"}
 
     hooks = CpuHooks()
+    if fault == "hang":
+        # the deadline fires while the main thread hangs in a collective: the line goes to a file (the process leaves with os._exit)
+        sys.stdout = open(out_path + ".%d" % rank, "w")
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--model", "tiny", "--deadline", "6", "--pg-timeout", "600"], hooks=hooks)
+        raise AssertionError("main() returned although a leg hangs")
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--model", "tiny"], hooks=hooks)
+    if fault == "raise":
+        if rank == 0:
+            q.put(json.loads(buf.getvalue().strip().splitlines()[-1]))
+        return
     assert hooks.stepper.n == 4                                 # warm-up + timed steps, every rank
     assert [c for c in calls if isinstance(c, str)] == ["prefill_sharded", "prefill_model_tp", "k_sharded_decode"]
     # replicas are seeded per rank; the tensor-parallel leg rebuilds the SAME checkpoint on every rank
@@ -195,3 +215,47 @@ def test_main_control_flow_two_ranks_gloo():
     for k in ("prefill_k_sharded", "decode_k_sharded", "continuous_batch", "prefill_model", "prefill_model_tp", "eval_ppl", "train_layer"):
         assert k in line, k
     assert line["decode_k_sharded"]["k_shards"] == 2 and line["decode_k_sharded"]["model"] == "LLaMA-13B shapes"
+
+
+def _spawn2(fault, out_path=None):
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, q, fault, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, p.exitcode
+    return q
+
+
+def test_failed_secondary_leg_is_recorded_and_nothing_else_is_lost():
+    """A secondary leg that raises (injected into rank 0's prefill_model leg): its field carries the error, every other field --
+    the headline, the legs every rank enters, cpu_baseline -- is there, and the job ends normally on both ranks."""
+    line = _spawn2("raise").get(timeout=5)
+    assert line["prefill_model"] == {"error": "RuntimeError: injected failure"}
+    assert line["value"] > 0 and "incomplete" not in line
+    for k in ("roofline", "cpu_baseline", "prefill_k_sharded", "decode_k_sharded", "continuous_batch", "prefill_model_tp", "eval_ppl", "decode_ctx"):
+        assert k in line and line[k] is not None, k
+
+
+def test_hung_secondary_leg_cannot_suppress_the_headline_line(tmp_path):
+    """Rank 1 never enters the config-4 leg's collective, rank 0 hangs in it: at the deadline rank 0 prints the ONE JSON line with
+    everything measured so far and `incomplete` naming the leg, both ranks exit with status 0."""
+    import json
+    out_path = str(tmp_path / "bench_out")
+    _spawn2("hang", out_path)
+    text = open(out_path + ".0").read().strip()
+    assert len(text.splitlines()) == 1
+    line = json.loads(text)
+    assert line["metric"] == "decode_tokens_per_sec" and line["value"] > 0 and line["n_gpus"] == 2
+    assert line["incomplete"]["legs_not_finished"] == ["decode_k_sharded"]
+    assert line["roofline"]["bound"] == "hbm" and line["prefill_k_sharded"]["k_shards"] == 2     # the legs before the hang survived
+    assert "decode_k_sharded" not in line
+    assert open(out_path + ".1").read().strip() == ""

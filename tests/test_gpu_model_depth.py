@@ -6,9 +6,9 @@ batched + 2 batched decode steps).  Weights regenerate bit-exactly from the seed
 
 This pins error growth through 32 x 7 LayerNorm-terminated 1-bit projections for every route of the build --
 module path, fused prefill route (row kernels + own attention), ``DecodeEngine`` (HIP graph and direct),
-``BatchedDecodeStep`` (one chain and two chains) -- against the reference itself.  Bar (round 5): 1.25 x the worst error
-measured for the golden over all routes (``tests/_parity_log.py``, ``profiles/r05_model_parity.txt``), never looser than
-rounds 1-4's ``max(2 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)``.  It replaces the round-1..3 comparison
+``BatchedDecodeStep`` (one chain and two chains) -- against the reference itself.  Bar (round 6): derived from the golden
+itself, ``max(1.6 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)`` (``tests/_parity_log.py`` says why 1.6; the errors
+measured per route are logged to ``profiles/r06_model_parity.txt``).  It replaces the round-1..3 comparison
 of the 32-layer engine with this repo's own module path.
 """
 import os

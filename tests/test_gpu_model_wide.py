@@ -4,9 +4,9 @@ reference's ``BitLlamaForCausalLMInf`` (modeling_bitllama.py:1512-1611) on the C
 tests/golden/gen_goldens_model_wide.py.  The weights are regenerated here from the same seed
 (``synthetic_state_dict(cfg, seed, device="cpu")`` is bit-reproducible); the fixture holds ids and logits only.
 
-Every decode / prefill route of the build is held to the bar of the tiny-model tests,
-1.25 x the worst error measured for the golden over all routes (round 5: ``tests/_parity_log.py``,
-``profiles/r05_model_parity.txt``), never looser than ``max(2 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)``:
+Every decode / prefill route of the build is held to a bar derived from the golden itself,
+``max(1.6 x the reference's own fp16-vs-fp32 gap, 2e-3 x logit scale)`` (``tests/_parity_log.py`` says why 1.6; the errors measured
+per route are logged to ``profiles/r06_model_parity.txt``):
   module path (eager), fused glue + fused attention on a 4096-token prompt (the LDS-DMA GEMM on producer-scaled
   rows), ``DecodeEngine`` (HIP graph and direct), ``BatchedDecodeStep`` at 32 slots, ``ContinuousBatcher``.
 """
@@ -33,7 +33,7 @@ def wide(golden_dir):
 
 def _tol(z, a="prefill_logits"):
     ref16, ref32 = z[a + "_f16"], z[a + "_f32"]
-    return max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
+    return __import__('_parity_log').loose_tol(ref16, ref32)
 
 
 def _chk(z, name, route, got, sl=None):
@@ -129,7 +129,7 @@ def test_batched_decode_step_32_slots(wide, prescaled_rows):
     cache = model.new_cache(B, max_len)
     lg = model(bids, cache)[:, -1].cpu().numpy()
     ref16, ref32 = z["batch_logits_f16"], z["batch_logits_f32"]
-    tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
+    tol = __import__('_parity_log').loose_tol(ref16, ref32)
     from _parity_log import check
     check("model_wide_c", "batch_prefill", "module path, 32 sequences", lg, ref16[:, 0], ref32[:, 0], loose=tol)
     step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True, prescaled_rows=prescaled_rows)
@@ -155,7 +155,7 @@ def test_continuous_batcher_tokens(wide):
     z, cfg, model = wide
     bids, toks = z["batch_ids"], z["batch_greedy_f16"]
     ref16, ref32 = z["batch_logits_f16"], z["batch_logits_f32"]
-    tol = max(2.0 * float(np.abs(ref16 - ref32).max()), 2e-3 * float(np.abs(ref32).max()))
+    tol = __import__('_parity_log').loose_tol(ref16, ref32)
     cb = ContinuousBatcher(model, max_batch=32, max_len=16)
     assert cb._native is not None
     rids = [cb.add_request(bids[b].tolist(), 4) for b in range(bids.shape[0])]
