@@ -154,6 +154,11 @@ int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *
                            int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
 int onebit_rows_swiglu(const void *u_gate, const void *u_up, const void *h_next_or_null, void *act, int64_t T,
                        int64_t I, float ln_eps, void *stream);
+/* ABI 9: onebit_rows_res_ln_rms for a producer WITH a bias (o_proj of a checkpoint with config.attention_bias):
+ * r = hres_in + fp16(LayerNorm(u_prev) + bias_prev) (bitnet.py:119-120, then modeling_bitllama.py:912).  bias_prev fp16 [H] or NULL. */
+int onebit_rows_res_ln_rms_bias(const void *hres_in, const void *u_prev, const void *bias_prev_or_null, const void *rms_w, void *hres_out,
+                                void *x_or_null, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
+                                int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream);
 /* 1 when a forward call of this shape may pass ONEBIT_FLAG_PRESCALED: fp16 calls that take the LDS-DMA prefill GEMM
  * (large T) or the LDS-DMA skinny GEMM (2 <= T <= 64, K % 128 == 0, K >= 512); the call itself also needs 16-byte
  * aligned packed rows / activations.  Every other kernel multiplies by input_factor on the way in and refuses the flag. */
@@ -276,7 +281,7 @@ typedef struct onebit_decode_state {
      * context as attn_splits workgroups of attn_chunk positions per head with an in-launch last-arriver combine
      * (onebit_attention_decode_rows; attn_scratch then holds onebit_attention_decode_scratch_bytes(1, n_heads, attn_splits) bytes,
      * zero-filled once) -- K and V are each read once, no score scratch; attn_splits * attn_chunk must cover the context + 1.
-     * attn_chunk == 0: the round-2 pair (scores kernel + P.V kernel, exact fp16 probabilities).  No q / k / v bias.       */
+     * attn_chunk == 0: the round-2 pair (scores kernel + P.V kernel, exact fp16 probabilities).                             */
     int32_t attn_chunk;
     void *q_rows;               /* fp16 [n_heads * head_dim]                                                               */
 } onebit_decode_state_t;
@@ -407,8 +412,11 @@ typedef struct onebit_seg { int32_t row0, n, slot, past; } onebit_seg_t;
  * (modeling_bitllama.py:175-181), k / v appended to cache row [row_slot[t]][kv head][row_pos[t]], q token-major [T, n_heads, D].
  * row_slot (NULL: slot = t) / row_pos: DEVICE int32 [T]; a row whose slot / position lies outside [0, n_slots) x [0, max_len)
  * is skipped (an idle decode slot).  caches [n_slots][n_kv_heads][max_len][head_dim]; cos / sin [max_pos >= max_len, head_dim]. */
+/* q_bias / k_bias / v_bias: the projections' biases of a checkpoint with config.attention_bias (modeling_bitllama.py:451-453), fp16
+ * [n_heads * D] / [n_kv_heads * D] x 2, all three or all NULL: q / k / v = fp16(LayerNorm(u) + b) (bitnet.py:118-120) before RoPE. */
 int onebit_rows_qkv_rope_ragged(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
                                 const int32_t *row_slot, const int32_t *row_pos, void *q, void *k_cache, void *v_cache,
+                                const void *q_bias, const void *k_bias, const void *v_bias,
                                 int64_t T, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots,
                                 int64_t max_len, int64_t max_pos, float ln_eps, void *stream);
 
@@ -442,7 +450,8 @@ int onebit_attention_decode_rows(const void *q, const void *k_cache, const void 
  * (slot, position); SiLU(LayerNorm) * LayerNorm), attention runs per item on its own cache slot (prompt chunks: causal flash
  * attention with past on MFMA; decode rows: split-KV), and the lm_head + greedy token run on the n_out rows that sample.
  * 9-13 launches per decoder layer whatever the number of items; no per-item loop on the host.
- * model->layers[l].k_cache / v_cache: [n_slots][n_kv_heads][max_len][head_dim].  No q / k / v biases (o bias is taken).  */
+ * model->layers[l].k_cache / v_cache: [n_slots][n_kv_heads][max_len][head_dim].  Checkpoints with config.attention_bias are
+ * taken (q / k / v biases in the rope kernel, the o bias in the norm kernel that consumes u_o).                              */
 typedef struct onebit_mixed_state {
     uint64_t struct_size;        /* sizeof(onebit_mixed_state_t) as the caller compiled it (checked)                          */
     int32_t n_rows;              /* token rows of the step                                                                    */

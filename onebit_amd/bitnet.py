@@ -161,10 +161,15 @@ class BitLinearInf(nn.Module):
             raise RuntimeError("pre_layernorm: the bias is added after the LayerNorm; use forward")
         return self.forward(input, _pre_ln=True)
 
-    def prescaled_ok(self, T: int, dtype=torch.float16) -> bool:
+    def pre_layernorm_bias_deferred(self, input: torch.Tensor, prescaled: bool = False) -> torch.Tensor:
+        """``pre_layernorm`` / ``pre_layernorm_prescaled`` of a layer WITH a bias, for a caller that adds ``self.bias`` itself after
+        the LayerNorm it fuses with what follows (onebit_rows_qkv_rope_ragged / onebit_rows_res_ln_rms_bias take the bias)."""
+        return self.forward(input, _pre_ln=True, _prescaled=prescaled)
+
+    def prescaled_ok(self, T: int, dtype=torch.float16, bias_deferred: bool = False) -> bool:
         """True when a T-row call of this layer may consume pre-scaled activations
         (``pre_layernorm_prescaled``): it takes the LDS-DMA GEMM, which reads fp16(x * h) rows."""
-        if self.bias is not None or dtype != torch.float16 or self.weight_scale.dtype != torch.float16:
+        if (self.bias is not None and not bias_deferred) or dtype != torch.float16 or self.weight_scale.dtype != torch.float16:
             return False
         if not self.weight.is_cuda or self.weight.stride(-1) != 1 or self.weight.stride(0) % 16 or self.weight.data_ptr() % 16:
             return False                                   # what the C side requires of the packed rows for the flag

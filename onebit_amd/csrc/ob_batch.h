@@ -275,6 +275,9 @@ struct ObQkvRopeArgs {
     // token-major.  A row whose slot / position lies outside [0, n_slots) x [0, max_len) is skipped (idle decode slot).
     const int *row_slot, *row_pos;       // device [T]; row_pos != NULL selects this form (S, past unused)
     int n_slots;
+    // (round 6) config.attention_bias (modeling_bitllama.py:451-453): q / k / v = fp16(LayerNorm(u) + b) (bitnet.py:118-120)
+    // BEFORE the rotary embedding; all three or none
+    const _Float16 *b_q, *b_k, *b_v;     // [H*D], [Hkv*D], [Hkv*D]
 };
 
 template <int NV>
@@ -322,6 +325,27 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
         qp8[v] = __builtin_bit_cast(ob_half8, qb);
         kp8[v] = __builtin_bit_cast(ob_half8, kb);
     }
+    const bool has_b = A.b_q != nullptr;                    // (uniform)
+    ob_half8 bq8[NV], bqp8[NV], bk8[NV], bkp8[NV], bv8[NV];
+    if (has_b) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int base = (v * OB_DEC_THREADS + tid) * 8;
+            const int bq = vq[v] ? base : 0, bk = vk[v] ? base : 0;
+            bq8[v] = *reinterpret_cast<const ob_half8 *>(A.b_q + bq);
+            bk8[v] = *reinterpret_cast<const ob_half8 *>(A.b_k + bk);
+            bv8[v] = *reinterpret_cast<const ob_half8 *>(A.b_v + bk);
+            const ob_u32x4 qa = __builtin_bit_cast(ob_u32x4, bq8[v]), ka = __builtin_bit_cast(ob_u32x4, bk8[v]);
+            ob_u32x4 qb, kb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qb[i] = (uint32_t)__shfl_xor((int)qa[i], D >> 4);
+                kb[i] = (uint32_t)__shfl_xor((int)ka[i], D >> 4);
+            }
+            bqp8[v] = __builtin_bit_cast(ob_half8, qb);
+            bkp8[v] = __builtin_bit_cast(ob_half8, kb);
+        }
+    }
     float mq, rq, mk, rk, mv, rv;
     if (A.ext) {                                            // uniform per launch
         const float *e = A.ext + (size_t)t * 6;
@@ -352,7 +376,8 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
             ob_half8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float x0 = ob_ln_apply((float)q8[v][i], mq, rq), x1 = ob_ln_apply((float)qp8[v][i], mq, rq);
+                float x0 = ob_ln_apply((float)q8[v][i], mq, rq), x1 = ob_ln_apply((float)qp8[v][i], mq, rq);
+                if (has_b) { x0 = ob_round_h(x0 + (float)bq8[v][i]); x1 = ob_round_h(x1 + (float)bqp8[v][i]); }
                 const float xr = d0 < half ? -x1 : x1;
                 o[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
             }
@@ -365,10 +390,15 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
             ob_half8 ok, ov;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float x0 = ob_ln_apply((float)k8[v][i], mk, rk), x1 = ob_ln_apply((float)kp8[v][i], mk, rk);
+                float x0 = ob_ln_apply((float)k8[v][i], mk, rk), x1 = ob_ln_apply((float)kp8[v][i], mk, rk);
+                float xv = ob_ln_apply((float)v8[v][i], mv, rv);
+                if (has_b) {
+                    x0 = ob_round_h(x0 + (float)bk8[v][i]); x1 = ob_round_h(x1 + (float)bkp8[v][i]);
+                    xv = ob_round_h(xv + (float)bv8[v][i]);
+                }
                 const float xr = d0 < half ? -x1 : x1;
                 ok[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
-                ov[i] = (_Float16)ob_ln_apply((float)v8[v][i], mv, rv);
+                ov[i] = (_Float16)xv;
             }
             const int64_t off = (((int64_t)b * A.Hkv + hd) * A.max_len + pos) * D + d0;
             *reinterpret_cast<ob_half8 *>(A.kcache + off) = ok;

@@ -94,14 +94,21 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
     };
     float m = -INFINITY, l = 0.f;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int base = p_lo; base < p_hi; base += OB_FD_PG * NI) {
-        ob_half8 k8[NI], v8[NI];
+    // the next sweep's rows are requested before the current sweep's arithmetic (two register sets): a split of several sweeps
+    // keeps 2 * NI loads per thread in flight instead of draining between sweeps
+    ob_half8 k8[NI], v8[NI], kn[NI], vn[NI];
+    auto fetch = [&](ob_half8 (&kd)[NI], ob_half8 (&vd)[NI], int base) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int64_t off = (int64_t)min(base + pg + OB_FD_PG * i, L - 1) * D;
-            k8[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(kb + off));
-            v8[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(vb + off));
+            kd[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(kb + off));
+            vd[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(vb + off));
         }
+    };
+    fetch(k8, v8, p_lo);
+    for (int base = p_lo; base < p_hi; base += OB_FD_PG * NI) {
+        const bool more = base + OB_FD_PG * NI < p_hi;                               // (uniform)
+        if (more) fetch(kn, vn, base + OB_FD_PG * NI);
         float sc[NI];
         float mx = -INFINITY;
 #pragma unroll
@@ -125,6 +132,10 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
             l += pe;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pe, (float)v8[i][e], o[e]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { k8[i] = kn[i]; v8[i] = vn[i]; }
         }
     }
     // ---- merge the workgroup's 16 rows: maximum, rescale, sums
@@ -173,20 +184,25 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
     __syncthreads();
     if (red[8] == 0.f) return;
     if (tid < D) {
-        float Mg = -INFINITY;
-        for (int s = 0; s < nlive; ++s) Mg = fmaxf(Mg, __hip_atomic_load(pml + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        float ls = 0.f, os = 0.f;
-        for (int s0 = 0; s0 < nlive; s0 += 4) {                                      // four partials in flight, fixed order
-            float pm[4], pl[4], pv[4];
+        // every partial of the (row, head) requested at once (16 per batch: {max, sum} and this thread's output element), then a
+        // fixed-order combine -- two dependent round trips (statistics, then outputs) would sit on the critical path of the step
+        float Mg = -INFINITY, ls = 0.f, os = 0.f;
+        for (int s0 = 0; s0 < nlive; s0 += 16) {
+            float pm[16], pl[16], pv[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 const int s = min(s0 + j, nlive - 1);
                 pm[j] = __hip_atomic_load(pml + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pl[j] = __hip_atomic_load(pml + 2 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pv[j] = __hip_atomic_load(pso + s * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            float mb = Mg;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 16; ++j) mb = fmaxf(mb, pm[j]);                      // (clamped duplicates do not change the maximum)
+            const float fo = Mg == -INFINITY ? 0.f : __expf(Mg - mb);                // rescale what earlier batches accumulated
+            ls *= fo; os *= fo; Mg = mb;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
                 if (s0 + j < nlive) {
                     const float w = __expf(pm[j] - Mg);
                     ls = __builtin_fmaf(pl[j], w, ls);

@@ -842,9 +842,9 @@ static int ob_single_token_gemv(const void *packed, int64_t ldw_bytes, const voi
     return ob_launch_dec_gemv(a, s);
 }
 
-extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
-                                      void *x, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
-                                      int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
+extern "C" int onebit_rows_res_ln_rms_bias(const void *hres_in, const void *u_prev, const void *bias_prev, const void *rms_w, void *hres_out,
+                                           void *x, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
+                                           int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
 {
     if (T < 0 || H <= 0 || n_scaled < 0 || n_scaled > 3) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: bad size");
     if (H % 8 != 0 || H > OB_DEC_MAXV * OB_DEC_THREADS * 8) return ob_fail(ONEBIT_E_SHAPE, "rows_res_ln_rms: H = %lld", (long long)H);
@@ -852,16 +852,24 @@ extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, c
     if (!hres_in || !u_prev || !rms_w || !hres_out || (!x && n_scaled == 0) || (n_scaled > 0 && (!h_next || !x_scaled)))
         return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null pointer");
     if (T > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: dimension too large");
+    if (bias_prev && !ob_aligned(bias_prev, 16)) return ob_fail(ONEBIT_E_ALIGN, "rows_res_ln_rms: bias must be 16-byte aligned");
     ObBNormArgs a = {};
     a.hres_in = (const _Float16 *)hres_in; a.u_prev = (const _Float16 *)u_prev; a.rms_w = (const _Float16 *)rms_w;
     a.hres_out = (_Float16 *)hres_out; a.x = (_Float16 *)x; a.H = (int)H; a.rms_eps = rms_eps; a.ln_eps = ln_eps;
-    a.n_scaled = n_scaled;
+    a.n_scaled = n_scaled; a.bias_prev = (const _Float16 *)bias_prev;
     for (int i = 0; i < n_scaled; ++i) {
         if (!h_next[i] || !x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_res_ln_rms: null scaled output %d", i);
         a.h_next[i] = (const _Float16 *)h_next[i]; a.x_scaled[i] = (_Float16 *)x_scaled[i];
     }
     OB_LAUNCH_NORM(false, H, dim3((unsigned)T), (hipStream_t)stream, a);
     return ob_launch_status("rows_res_ln_rms");
+}
+
+extern "C" int onebit_rows_res_ln_rms(const void *hres_in, const void *u_prev, const void *rms_w, void *hres_out,
+                                      void *x, const void *const *h_next, void *const *x_scaled, int32_t n_scaled,
+                                      int64_t T, int64_t H, float rms_eps, float ln_eps, void *stream)
+{
+    return onebit_rows_res_ln_rms_bias(hres_in, u_prev, nullptr, rms_w, hres_out, x, h_next, x_scaled, n_scaled, T, H, rms_eps, ln_eps, stream);
 }
 
 extern "C" int onebit_rows_swiglu_stats(const void *u_gate, const void *u_up, const void *h_next, const float *row_stats, void *act,
@@ -936,7 +944,7 @@ extern "C" int onebit_rows_qkv_rope_stats(const void *u_q, const void *u_k, cons
 // Ragged rows (ABI 9): LayerNorm + RoPE + cache append for the token rows of SEVERAL sequences -- row t -> (row_slot[t], row_pos[t])
 extern "C" int onebit_rows_qkv_rope_ragged(const void *u_q, const void *u_k, const void *u_v, const void *cos, const void *sin,
                                            const int32_t *row_slot, const int32_t *row_pos, void *q, void *k_cache, void *v_cache,
-                                           int64_t T, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots,
+                                           const void *q_bias, const void *k_bias, const void *v_bias, int64_t T, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots,
                                            int64_t max_len, int64_t max_pos, float ln_eps, void *stream)
 {
     if (T < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || n_slots <= 0 || max_len <= 0) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: bad size");
@@ -950,9 +958,13 @@ extern "C" int onebit_rows_qkv_rope_ragged(const void *u_q, const void *u_k, con
         !ob_aligned(cos, 16) || !ob_aligned(sin, 16))
         return ob_fail(ONEBIT_E_ALIGN, "rows_qkv_rope_ragged: tensors must be 16-byte aligned");
     if (T > 0x7fffffffLL || max_len > 0x7fffffffLL || n_slots > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: dimension too large");
+    if ((q_bias || k_bias || v_bias) && !(q_bias && k_bias && v_bias)) return ob_fail(ONEBIT_E_ARG, "rows_qkv_rope_ragged: some but not all of q_bias / k_bias / v_bias");
+    if (q_bias && (!ob_aligned(q_bias, 16) || !ob_aligned(k_bias, 16) || !ob_aligned(v_bias, 16)))
+        return ob_fail(ONEBIT_E_ALIGN, "rows_qkv_rope_ragged: biases must be 16-byte aligned");
     ObQkvRopeArgs a = {(const _Float16 *)u_q, (const _Float16 *)u_k, (const _Float16 *)u_v, (const _Float16 *)cos, (const _Float16 *)sin,
                        (_Float16 *)q, (_Float16 *)k_cache, (_Float16 *)v_cache, 1, n_heads, n_kv_heads, head_dim, 0,
-                       (int)max_len, 1, ln_eps, nullptr, row_slot, row_pos, (int)n_slots};
+                       (int)max_len, 1, ln_eps, nullptr, row_slot, row_pos, (int)n_slots,
+                       (const _Float16 *)q_bias, (const _Float16 *)k_bias, (const _Float16 *)v_bias};
     OB_LAUNCH_QKVROPE((int64_t)n_heads * head_dim, dim3((unsigned)T), (hipStream_t)stream, a);
     return ob_launch_status("rows_qkv_rope_ragged");
 }
@@ -1282,11 +1294,11 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         if (st->attn_splits > 0) {
             // key-block form (ABI 9): LayerNorm + RoPE + cache append per slot, then (head, slot, split) workgroups
             const void *h_o = sk3 ? L.o.input_factor : nullptr;
-            if (L.q_bias || L.k_bias || L.v_bias)
-                return ob_fail(ONEBIT_E_ARG, "decode_step_batched: attn_splits with q / k / v biases (layer %d): use attn_splits = 0", l);
+            if ((L.q_bias || L.k_bias || L.v_bias) && !(L.q_bias && L.k_bias && L.v_bias))
+                return ob_fail(ONEBIT_E_ARG, "decode_step_batched: layer %d has some but not all of q_bias / k_bias / v_bias", l);
             const int chunk = st->attn_chunk > 0 ? st->attn_chunk : 256;
             if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, at.kcache, at.vcache,
-                                                  B, m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, m->ln_eps, s)))
+                                                  L.q_bias, L.k_bias, L.v_bias, B, m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, m->ln_eps, s)))
                 return rc;
             if ((rc = onebit_attention_decode_rows(st->q_rows, at.kcache, at.vcache, st->attn_out, h_o, nullptr, st->pos, B, m->n_heads, m->n_kv_heads, D,
                                                    B, m->max_len, chunk, st->attn_splits, st->attn_scratch,
@@ -1655,9 +1667,8 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         if (rope_cur) at.rope_cur = (const _Float16 *)st->rope_cur;
         at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
         if (keyblock) {
-            if (qkv_bias) return ob_fail(ONEBIT_E_ARG, "decode_step: the key-block attention takes no q / k / v bias (layer %d): use attn_chunk = 0", l);
             if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, L.k_cache, L.v_cache,
-                                                  1, m->n_heads, m->n_kv_heads, D, 1, m->max_len, m->max_len, m->ln_eps, s)))
+                                                  L.q_bias, L.k_bias, L.v_bias, 1, m->n_heads, m->n_kv_heads, D, 1, m->max_len, m->max_len, m->ln_eps, s)))
                 return rc;
             if ((rc = onebit_attention_decode_rows(st->q_rows, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads, m->n_kv_heads, D,
                                                    1, m->max_len, st->attn_chunk, st->attn_splits, st->attn_scratch,

@@ -87,7 +87,9 @@ static int ob_fdec_launch(const void *q, const void *k_cache, const void *v_cach
         a.part_ml = (float *)p; p += ob_align256(rh * n_splits * 2 * 4);
         a.part_o = (float *)p;
     }
-    hipLaunchKernelGGL((ob_fdec_kernel<4>), dim3((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits), dim3(OB_FD_THREADS), 0, stream, a);
+    // keys per thread in flight: a 128-position multiple sweeps 8 per thread (one round trip per 128 positions), else 4
+    if (chunk % 128 == 0) hipLaunchKernelGGL((ob_fdec_kernel<8>), dim3((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits), dim3(OB_FD_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((ob_fdec_kernel<4>), dim3((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits), dim3(OB_FD_THREADS), 0, stream, a);
     return ob_launch_status("attention_decode_rows");
 }
 
@@ -227,9 +229,8 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
             return ob_fail(ONEBIT_E_ARG, "mixed_step: null pointer in layer %d", l);
-        if (L.q_bias || L.k_bias || L.v_bias)
-            return ob_fail(ONEBIT_E_ARG, "mixed_step: layer %d has q / k / v biases (config.attention_bias): not taken by the ragged rope kernel -- "
-                                         "run such checkpoints through the module path", l);
+        if ((L.q_bias || L.k_bias || L.v_bias) && !(L.q_bias && L.k_bias && L.v_bias))
+            return ob_fail(ONEBIT_E_ARG, "mixed_step: layer %d has some but not all of q_bias / k_bias / v_bias", l);
         if ((rc = check(L.q, H, NQ, "q", l)) || (rc = check(L.k, H, NK, "k", l)) || (rc = check(L.v, H, NK, "v", l)) || (rc = check(L.o, NQ, H, "o", l)) ||
             (rc = check(L.gate, H, I, "gate", l)) || (rc = check(L.up, H, I, "up", l)) || (rc = check(L.down, I, H, "down", l)))
             return rc;
@@ -255,7 +256,7 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         }
         // 3. LayerNorm(q, k, v) + RoPE + cache append, every row at its own (slot, position)
         if ((rc = onebit_rows_qkv_rope_ragged(w.uq, w.uk, w.uv, m->rope_cos, m->rope_sin, st->row_slot, st->row_pos, w.q, L.k_cache, L.v_cache,
-                                              T, m->n_heads, m->n_kv_heads, D, st->n_slots, m->max_len, m->max_len, m->ln_eps, s)))
+                                              L.q_bias, L.k_bias, L.v_bias, T, m->n_heads, m->n_kv_heads, D, st->n_slots, m->max_len, m->max_len, m->ln_eps, s)))
             return rc;
         // 4. attention: prompt chunks on the MFMA flash kernel, single-token rows on the split-KV decode kernel
         const void *h_o = pres_o ? L.o.input_factor : nullptr;

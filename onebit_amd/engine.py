@@ -204,8 +204,7 @@ class DecodeEngine:
         ``long_attention``: "keyblock" (round 6, default: LayerNorm + RoPE + cache append in one launch, then
         ``onebit_attention_decode_rows`` -- ``attn_chunk`` positions per workgroup, K and V read once, last-arriver combine; one
         HIP graph per power-of-two split count, chosen per step by the host-known position) or "pair" (round 2: scores kernel +
-        P.V kernel with ``attn_splits`` splits, the reference's fp16 probability rounding; also what a checkpoint with
-        q / k / v biases takes)."""
+        P.V kernel with ``attn_splits`` splits, the reference's fp16 probability rounding)."""
         if long_attention not in ("keyblock", "pair"):
             raise ValueError("long_attention must be 'keyblock' or 'pair'")
         cfg = model.config
@@ -274,9 +273,7 @@ class DecodeEngine:
                         self.graph64 = g
                     else:
                         self.graph = g
-        has_bias = any(pr.bias is not None for layer in model.model.layers
-                       for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj))
-        self._keyblock = long_attention == "keyblock" and not has_bias and bool(self._long_from)
+        self._keyblock = long_attention == "keyblock" and bool(self._long_from)
         self._kb_graphs, self._kb_states = {}, {}
         if self._keyblock:
             # one state / graph per power-of-two split count: splits * attn_chunk covers the step's context + 1
@@ -537,8 +534,6 @@ class MixedStep:
             raise ValueError("MixedStep: head_dim must be 64 or 128 and hidden a multiple of 64")
         if max_len > cfg.max_position_embeddings:
             raise ValueError("max_len exceeds max_position_embeddings (the rope tables have that many rows)")
-        if any(pr.bias is not None for layer in model.model.layers for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj)):
-            raise ValueError("MixedStep: q / k / v biases (config.attention_bias) are not taken by the ragged rope kernel")
         self.model, self.cfg, self.dev = model, cfg, p.device
         self.n_slots, self.max_len, self.attn_chunk = int(n_slots), int(max_len), int(attn_chunk)
         if -(-self.max_len // self.attn_chunk) > 64:

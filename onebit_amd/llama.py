@@ -161,7 +161,8 @@ class LlamaAttentionInf(nn.Module):
     def forward(self, hidden_states, cos, sin, kv: Tuple[torch.Tensor, torch.Tensor], past_len: int,
                 pre_ln_out: bool = False):
         B, S, _ = hidden_states.shape
-        o_proj = self.o_proj.pre_layernorm if pre_ln_out else self.o_proj
+        # pre_ln_out: the caller fuses o_proj's LayerNorm (and adds its bias, if any) with what follows (onebit_rows_res_ln_rms_bias)
+        o_proj = self.o_proj.pre_layernorm_bias_deferred if pre_ln_out else self.o_proj
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_dim
         q = self.q_proj(hidden_states).view(B, S, H, D).transpose(1, 2)
         k = self.k_proj(hidden_states).view(B, S, Hkv, D).transpose(1, 2)
@@ -299,33 +300,39 @@ class OneBitLlamaForCausalLM(nn.Module):
         cos, sin = self._rope_tables(h.device, h.dtype, past + S)
         sp = _stream_ptr(h.device)
 
-        def res_ln_rms(hres, u, w, consumers=()):
-            """hres + LayerNorm(u) -> new residual; RMSNorm -> x.  ``consumers``: projections that read x; when all of
-            them take pre-scaled rows at this T the kernel writes fp16(x * h_i) for each instead of x and they run
-            with ONEBIT_FLAG_PRESCALED (no separate scaling pass).  Returns (residual, x or None, [a_i] or None)."""
+        def res_ln_rms(hres, u, w, consumers=(), bias_prev=None):
+            """hres + LayerNorm(u) (+ bias_prev: the bias of the projection that produced u) -> new residual; RMSNorm -> x.
+            ``consumers``: projections that read x; when all of them take pre-scaled rows at this T the kernel writes
+            fp16(x * h_i) for each instead of x and they run with ONEBIT_FLAG_PRESCALED (no separate scaling pass).
+            Returns (residual, x or None, [a_i] or None)."""
             hout = torch.empty_like(hres)
-            pres = bool(consumers) and all(p.prescaled_ok(T, hres.dtype) for p in consumers)
+            pres = bool(consumers) and all(p.prescaled_ok(T, hres.dtype, bias_deferred=True) for p in consumers)
             x = None if pres else torch.empty_like(hres)
             xs = [torch.empty_like(hres) for _ in consumers] if pres else []
             hp = (ctypes.c_void_p * 3)(*[p.input_factor.data_ptr() for p in consumers][:len(xs)])
             xp = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in xs])
             with torch.cuda.device(h.device):
-                _lib.check(lib.onebit_rows_res_ln_rms(hres.data_ptr(), u.data_ptr(), w.data_ptr(), hout.data_ptr(),
-                                                      None if x is None else x.data_ptr(), hp, xp, len(xs),
-                                                      T, H, cfg.rms_norm_eps, 1e-5, sp), "onebit_rows_res_ln_rms")
+                _lib.check(lib.onebit_rows_res_ln_rms_bias(hres.data_ptr(), u.data_ptr(), None if bias_prev is None else bias_prev.data_ptr(),
+                                                           w.data_ptr(), hout.data_ptr(), None if x is None else x.data_ptr(), hp, xp, len(xs),
+                                                           T, H, cfg.rms_norm_eps, 1e-5, sp), "onebit_rows_res_ln_rms")
             return hout, x, (xs if pres else None)
 
         def proj(p, x, a):
-            return p.pre_layernorm_prescaled(a) if a is not None else p.pre_layernorm(x)
+            # (a projection's bias -- q / k / v of a checkpoint with config.attention_bias -- joins its LayerNorm in the rope kernel)
+            return p.pre_layernorm_bias_deferred(a, prescaled=True) if a is not None else p.pre_layernorm_bias_deferred(x)
+
+        row_arrays = None          # (slot, position) of every token row: the ragged rope kernel, which takes the q / k / v biases
 
         x, xs = m.layers[0].input_layernorm(h), None
         u_down = None
         for li, (layer, kv) in enumerate(zip(m.layers, cache.layers)):
             att = layer.self_attn
+            qkv_bias = att.q_proj.bias is not None
+            if qkv_bias != (att.k_proj.bias is not None) or qkv_bias != (att.v_proj.bias is not None):
+                raise ValueError("fused glue: a bias on all of q / k / v_proj or on none (config.attention_bias)")
             fused_attn = (att.attn_impl in ("sdpa", "hip") and S > 1 and (past == 0 or att.attn_impl == "hip")
                           and (att.attn_impl == "sdpa" or att.head_dim in (64, 128))
-                          and att.q_proj.bias is None and att.k_proj.bias is None
-                          and att.v_proj.bias is None and kv[0].is_contiguous() and kv[1].is_contiguous()
+                          and kv[0].is_contiguous() and kv[1].is_contiguous()
                           and att.head_dim >= 16 and att.head_dim & (att.head_dim - 1) == 0
                           # onebit_rows_qkv_rope writes rows [b < B][kv head][past + s][D] through raw pointers: the
                           # cache must really have B slots of that geometry in the activations' dtype (a batch-1
@@ -346,25 +353,36 @@ class OneBitLlamaForCausalLM(nn.Module):
                 q = torch.empty((B, S, Hh, D), dtype=h.dtype, device=h.device)     # token-major: sdpa returns the same layout
                 kc, vc = kv
                 with torch.cuda.device(h.device):
-                    _lib.check(lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                                        q.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past,
-                                                        kc.shape[2], cos.shape[0], 1e-5, _lib.FLAG_Q_TOKEN_MAJOR, sp), "onebit_rows_qkv_rope")
+                    if qkv_bias:
+                        # biases join the LayerNorm inside the ragged form of the kernel: row t = (b, s) -> slot b, position past + s
+                        if row_arrays is None:
+                            ar = torch.arange(T, device=h.device, dtype=torch.int32)
+                            row_arrays = ((ar // S).contiguous(), (past + ar % S).contiguous())
+                        bq, bk, bv = (p_.bias.to(h.dtype).contiguous() for p_ in (att.q_proj, att.k_proj, att.v_proj))
+                        _lib.check(lib.onebit_rows_qkv_rope_ragged(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                                   row_arrays[0].data_ptr(), row_arrays[1].data_ptr(), q.data_ptr(), kc.data_ptr(),
+                                                                   vc.data_ptr(), bq.data_ptr(), bk.data_ptr(), bv.data_ptr(), T, Hh, Hkv, D,
+                                                                   kc.shape[0], kc.shape[2], cos.shape[0], 1e-5, sp), "onebit_rows_qkv_rope_ragged")
+                    else:
+                        _lib.check(lib.onebit_rows_qkv_rope(u_q.data_ptr(), u_k.data_ptr(), u_v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                            q.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, S, Hh, Hkv, D, past,
+                                                            kc.shape[2], cos.shape[0], 1e-5, _lib.FLAG_Q_TOKEN_MAJOR, sp), "onebit_rows_qkv_rope")
                 if att.attn_impl == "hip":
                     # own flash kernel: rows come back token-major, already multiplied by o_proj's input_factor when o_proj
                     # takes pre-scaled rows at this T (no separate scaling pass left on the route)
-                    o_pres = att.o_proj.prescaled_ok(T, h.dtype)
+                    o_pres = att.o_proj.prescaled_ok(T, h.dtype, bias_deferred=True)
                     o = hip_attention_prefill(q, kc, vc, past, att.o_proj.input_factor if o_pres else None).view(T, Hh * D)
-                    u_o = att.o_proj.pre_layernorm_prescaled(o) if o_pres else att.o_proj.pre_layernorm(o)
+                    u_o = att.o_proj.pre_layernorm_bias_deferred(o, prescaled=o_pres)
                 else:
                     keys, vals = kc[:B, :, :S], vc[:B, :, :S]
                     if Hkv != Hh:
                         keys, vals = keys.repeat_interleave(Hh // Hkv, dim=1), vals.repeat_interleave(Hh // Hkv, dim=1)
                     o = nn.functional.scaled_dot_product_attention(q.transpose(1, 2), keys, vals, is_causal=True)
-                    u_o = att.o_proj.pre_layernorm(o.transpose(1, 2).contiguous().reshape(T, Hh * D))    # (no copy when o is token-major)
+                    u_o = att.o_proj.pre_layernorm_bias_deferred(o.transpose(1, 2).contiguous().reshape(T, Hh * D))    # (no copy when o is token-major)
             else:
                 u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
             mlp = layer.mlp
-            h, x, xs = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight, (mlp.gate_proj, mlp.up_proj))
+            h, x, xs = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight, (mlp.gate_proj, mlp.up_proj), bias_prev=att.o_proj.bias)
             ag, au = xs if xs is not None else (None, None)
             u_g, u_u = proj(mlp.gate_proj, x, ag), proj(mlp.up_proj, x, au)
             act = torch.empty_like(u_g)

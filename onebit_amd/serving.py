@@ -231,7 +231,7 @@ class ContinuousBatcher:
         # native MIXED step (onebit_mixed_step): every step that carries prompt tokens -- the workload that defines BASELINE
         # config 5 -- runs on the HIP kernels (one GEMM per projection over all scheduled rows, fused row glue, ragged attention,
         # lm_head on the sampling rows); `_forward` below (torch glue in the reference's op order) remains for native=False and
-        # for checkpoints the native step refuses (q / k / v biases, head_dim other than 64 / 128, fp32 parameters)
+        # for checkpoints the native step refuses (head_dim other than 64 / 128, in_features % 32 != 0, fp32 parameters)
         self._mixed = None
         self.mixed_steps = 0
         self.time_mixed = self.time_decode = 0.0     # wall seconds in steps with / without prompt tokens (each step ends in a host sync)
@@ -247,10 +247,6 @@ class ContinuousBatcher:
         """The native step with key-block attention for ``splits`` splits of ``attn_chunk`` positions (built on first use)."""
         from .engine import BatchedDecodeStep
         if splits not in self._long:
-            has_bias = any(pr.bias is not None for layer in self.model.model.layers
-                           for pr in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj))
-            if has_bias:
-                raise ValueError("key-block attention takes no q / k / v bias")
             self._long[splits] = [BatchedDecodeStep(self.model, self.cache, self.sched.max_batch, self.sched.max_len,
                                                     attn_splits=splits, attn_chunk=self.attn_chunk), None]
         return self._long[splits][0]

@@ -329,7 +329,8 @@ def test_engine_accepts_fp32_checkpoint(golden_dir):
         BatchedDecodeStep(m32, m32.new_cache(2, 16).layers, 2, 16)
 
 
-@pytest.mark.parametrize("route", ["module", "engine", "engine graph", "engine split-kv", "batched", "batched no-stats", "batched unscaled"])
+@pytest.mark.parametrize("route", ["module", "engine", "engine graph", "engine split-kv", "engine key-block", "batched", "batched no-stats",
+                                   "batched unscaled", "batched key-block", "fused prefill", "mixed step"])
 def test_attention_bias_checkpoint_vs_reference(golden_dir, route):
     """config.attention_bias = True (modeling_bitllama.py:451-454: q / k / v / o_proj are built with a bias, added after the
     projection's LayerNorm, bitnet.py:119-120).  Round 4 refused such checkpoints in the fused engines; now the attention
@@ -361,10 +362,38 @@ def test_attention_bias_checkpoint_vs_reference(golden_dir, route):
         dec0 = model(tk[:, 0:1], cache0).cpu().numpy()
         assert np.abs(dec0[0, 0] - ref16[0]).max() > 4 * tol
         return
+    if route == "fused prefill":
+        # round 6: the fused prefill glue takes the biases too (q / k / v in the ragged rope kernel, o in onebit_rows_res_ln_rms_bias)
+        model.set_attention("hip").set_fused_glue(True)
+        cache = model.new_cache(1, 32)
+        lg = model(ids, cache).cpu().numpy()
+        assert np.abs(lg - z["prefill_logits_f16"]).max() <= tol
+        tk = torch.from_numpy(z["greedy_f16"]).to(dev)
+        dec = np.concatenate([model(tk[:, i:i + 1], cache).cpu().numpy() for i in range(4)], axis=1)
+        assert np.abs(dec[0] - ref16).max() <= tol
+        return
+    if route == "mixed step":
+        # round 6: onebit_mixed_step -- the prompt as one chunk in slot 2, then teacher-forced single-token steps next to a second request
+        from onebit_amd.engine import MixedStep
+        cfg = model.config
+        shape = (3, cfg.num_key_value_heads, 32, cfg.head_dim)
+        caches = [(torch.zeros(shape, dtype=torch.float16, device=dev), torch.zeros(shape, dtype=torch.float16, device=dev)) for _ in range(cfg.num_hidden_layers)]
+        ms = MixedStep(model, caches, 3, 32, keep_logits=True)
+        nxt = ms.launch([(2, 0, ids[0].tolist())])
+        torch.cuda.synchronize()
+        assert np.abs(ms.logits[0].float().cpu().numpy() - z["prefill_logits_f16"][0, -1]).max() <= tol and int(nxt[0]) == int(toks[0])
+        for i in range(4):
+            ms.launch([(0, 0, ids[0, :5].tolist()), (2, S + i, [int(toks[i])])] if i == 1 else [(2, S + i, [int(toks[i])])])
+            torch.cuda.synchronize()
+            lg = ms.logits[1 if i == 1 else 0].float().cpu().numpy()
+            assert np.abs(lg - ref16[i]).max() <= tol, (i, float(np.abs(lg - ref16[i]).max()), tol)
+        return
     if route.startswith("engine"):
         kw = dict(use_graph=route == "engine graph")
         if route == "engine split-kv":
-            kw.update(long_context_from=4, attn_splits=2)        # every step on the two split-KV launches
+            kw.update(long_context_from=4, attn_splits=2, long_attention="pair")        # every step on the two split-KV launches
+        if route == "engine key-block":
+            kw.update(long_context_from=4, long_attention="keyblock", attn_chunk=64)    # rope / append launch + key-block attention
         eng = DecodeEngine(model, max_len=64, **kw)
         eng.prefill(ids)
         assert eng.first_token == int(toks[0])
@@ -380,7 +409,8 @@ def test_attention_bias_checkpoint_vs_reference(golden_dir, route):
     cache = model.new_cache(B, max_len)
     model(ids.repeat(B, 1), cache)
     step = BatchedDecodeStep(model, cache.layers, B, max_len, sample=True, keep_logits=True,
-                             producer_stats=route != "batched no-stats", prescaled_rows=route != "batched unscaled")
+                             producer_stats=route != "batched no-stats", prescaled_rows=route != "batched unscaled",
+                             attn_splits=1 if route == "batched key-block" else 0, attn_chunk=64)
     for i in range(4):
         step.tokens.fill_(int(toks[i]))
         step.pos.fill_(S + i)

@@ -62,8 +62,8 @@ def test_rope_ragged_is_the_uniform_kernel_on_the_same_rows(H, Hkv, D):
     v1 = torch.zeros_like(k0)
     uq1, uk1, uv1 = pad(uq), pad(uk), pad(uv)
     L.check(lib.onebit_rows_qkv_rope_ragged(uq1.data_ptr(), uk1.data_ptr(), uv1.data_ptr(), cos.data_ptr(), sin.data_ptr(), row_slot.data_ptr(),
-                                            row_pos.data_ptr(), q1.data_ptr(), k1.data_ptr(), v1.data_ptr(), T + 1, H, Hkv, D, slots, max_len,
-                                            max_len, 1e-5, _sp()), "rope ragged")
+                                            row_pos.data_ptr(), q1.data_ptr(), k1.data_ptr(), v1.data_ptr(), None, None, None, T + 1, H, Hkv, D, slots,
+                                            max_len, max_len, 1e-5, _sp()), "rope ragged")
     torch.cuda.synchronize()
     assert torch.equal(q1[:T], q0)
     assert float(q1[T].abs().max()) == 0.0                                  # the idle row wrote nothing
