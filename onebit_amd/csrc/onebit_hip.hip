@@ -588,6 +588,15 @@ int ob_cu_count()
     return cus[dev];
 }
 
+// the kernels read the biases of a checkpoint with config.attention_bias as 16-byte vectors (advisor, round 5)
+static int ob_check_bias_align(const onebit_layer_t &L, const char *fn, int l)
+{
+    if ((L.q_bias && !ob_aligned(L.q_bias, 16)) || (L.k_bias && !ob_aligned(L.k_bias, 16)) || (L.v_bias && !ob_aligned(L.v_bias, 16)) ||
+        (L.o_bias && !ob_aligned(L.o_bias, 16)))
+        return ob_fail(ONEBIT_E_ALIGN, "%s: the biases of layer %d must be 16-byte aligned", fn, l);
+    return 0;
+}
+
 static int ob_fill_proj(ObProj &d, const onebit_proj_t &s, void *u, const char *name, float *st = nullptr)
 {
     d.st = (s.N % 16 == 0) ? st : nullptr;      // tile partials exist for whole 16-row tiles only
@@ -1242,6 +1251,7 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
             return ob_fail(ONEBIT_E_ARG, "decode_step_batched: null pointer in layer %d", l);
+        if ((rc = ob_check_bias_align(L, "decode_step_batched", l))) return rc;
         S3 qs = {{nullptr, nullptr, nullptr}};
         if (st->qkv_stats && NQ % 16 == 0 && NK % 16 == 0) {
             const size_t fq = (size_t)ob_tile_stats_floats(NQ), fk = (size_t)ob_tile_stats_floats(NK);
@@ -1628,6 +1638,7 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         const bool qkv_bias = L.q_bias || L.k_bias || L.v_bias;
         if (qkv_bias && !(L.q_bias && L.k_bias && L.v_bias))
             return ob_fail(ONEBIT_E_ARG, "decode_step: layer %d has some but not all of q_bias / k_bias / v_bias", l);
+        if ((rc = ob_check_bias_align(L, "decode_step", l))) return rc;
         // K1: residual (+LN of previous down) -> RMSNorm -> q, k, v
         ObGemvArgs a = {};
         a.nproj = 3; a.K = H;
@@ -1761,9 +1772,9 @@ static int ob_kshard_proj(ObProj &d, const onebit_proj_t &sp, float *z, int64_t 
     if (!sp.weight || !sp.input_factor || !sp.weight_scale || !z)
         return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: null pointer in projection %s", name);
     if (sp.N != n_expect || sp.K <= 0 || sp.K > k_full || sp.K % 128 != 0 || sp.ldw_bytes % 16 != 0 || sp.ldw_bytes < sp.K / 8 ||
-        !ob_aligned(sp.weight, 16) || !ob_aligned(sp.input_factor, 16))
+        !ob_aligned(sp.weight, 16) || !ob_aligned(sp.input_factor, 16) || !ob_aligned(sp.weight_scale, 16))
         return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: projection %s: the K slice must be a multiple of 128 columns with 16-byte "
-                                       "aligned weight rows and input_factor (N = %lld, K = %lld of %lld, pitch %lld)", name,
+                                       "aligned weight rows, input_factor and weight_scale (N = %lld, K = %lld of %lld, pitch %lld)", name,
                        (long long)sp.N, (long long)sp.K, (long long)k_full, (long long)sp.ldw_bytes);
     d.w = (const uint32_t *)sp.weight; d.h = (const _Float16 *)sp.input_factor; d.g = (const _Float16 *)sp.weight_scale;
     d.u = (_Float16 *)z;                       // ZOUT instances: fp32 partial sums
@@ -1839,6 +1850,7 @@ extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit
     const bool qkv_bias = L.q_bias || L.k_bias || L.v_bias;
     if (qkv_bias && !(L.q_bias && L.k_bias && L.v_bias))
         return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: layer %d has some but not all of q_bias / k_bias / v_bias", l);
+    { const int rcb = ob_check_bias_align(L, "decode_step_ksharded", l); if (rcb) return rcb; }
     ObGemvArgs a = {};
     a.prologue = OB_P_PLAIN; a.zout = 1; a.rms_eps = m->rms_eps; a.ln_eps = m->ln_eps;
     ObBNormArgs na = {};
