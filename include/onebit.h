@@ -442,6 +442,18 @@ int onebit_attention_decode_rows(const void *q, const void *k_cache, const void 
                                  int32_t head_dim, int64_t n_slots, int64_t max_len, int32_t chunk, int32_t n_splits, void *scratch,
                                  size_t scratch_bytes, void *stream);
 
+/* The same with the query formed INSIDE the attention launch (no separate rope / append launch): u_q / u_k / u_v are the pre-LayerNorm
+ * projection rows [rows, n_heads * D] / [rows, n_kv_heads * D] x 2, st_q / st_k / st_v the producer's per-16-row-tile LayerNorm partials
+ * of those rows (ob_tile layout of onebit_decode_state_t.tile_stats / onebit_batch_state_t.qkv_stats: ceil(n / 4096) * 512 floats per
+ * row); every (head, row, split) workgroup normalises and rotates its own head's query, the workgroup of the last live split forms the
+ * new key / value, attends to them from LDS and -- one workgroup per kv head -- appends them to the cache.  Biases as above. */
+int onebit_attention_decode_rows_fused(const void *u_q, const void *u_k, const void *u_v, const float *st_q, const float *st_k,
+                                       const float *st_v, const void *q_bias, const void *k_bias, const void *v_bias,
+                                       const void *cos, const void *sin, void *k_cache, void *v_cache, void *o, const void *h_next_or_null,
+                                       const int32_t *row_slot, const int32_t *row_pos, int64_t rows, int32_t n_heads, int32_t n_kv_heads,
+                                       int32_t head_dim, int64_t n_slots, int64_t max_len, int64_t max_pos, int32_t chunk, int32_t n_splits,
+                                       float ln_eps, void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- mixed prefill + decode step (BASELINE config 5: "mixed prefill+decode continuous batch") ---------------------------
  * ONE scheduler step on native kernels: the token rows of all scheduled items -- first the single next token of every decoding
  * request (n_dec rows), then the prompt chunks of the requests still entering (n_seg segments) -- go through every 1-bit

@@ -52,6 +52,8 @@ SYMBOLS = {
     "onebit_attention_decode_scratch_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, ctypes.c_int32]),
     "onebit_attention_decode_rows": (_int, [_vp] * 7 + [_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, ctypes.c_int32, ctypes.c_int32,
                                                       _vp, ctypes.c_size_t, _vp]),
+    "onebit_attention_decode_rows_fused": (_int, [_vp] * 17 + [_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_int32,
+                                                            ctypes.c_int32, _f, _vp, ctypes.c_size_t, _vp]),
     "onebit_mixed_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, ctypes.c_int32, ctypes.c_int32]),
     "onebit_mixed_step": (_int, [_vp, _vp, _vp]),     # (onebit_model_t*, onebit_mixed_state_t*, stream)
     "onebit_attn_scratch_bytes": (ctypes.c_size_t, [_vp, _int]),

@@ -23,6 +23,7 @@
 #pragma once
 #include <type_traits>
 #include "ob_common.h"
+#include "ob_rowstats.h"
 
 #ifndef OB_DEC_THREADS
 #define OB_DEC_THREADS 512
@@ -144,10 +145,7 @@ __device__ __forceinline__ void ob_ln_stats(float s1, float s2, float c, int n, 
     rstd = __builtin_amdgcn_rsqf(var + eps);
 }
 
-__device__ __forceinline__ float ob_ln_apply(float u, float mean, float rstd)
-{
-    return ob_round_h((u - mean) * rstd);
-}
+// (ob_ln_apply: ob_rowstats.h)
 
 // The same LayerNorm element as ONE instruction (v_fma_mixlo_f16: fp16 in, fp32 fma, fp16 out):
 // fp16(u * rstd + (-mean * rstd)).  One rounding of the normalised value instead of two; the forms
@@ -272,43 +270,7 @@ __device__ __forceinline__ void ob_tiles_slot_merge(const float *slot, int vec, 
     rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
 }
 
-// The same for a vector whose length is a runtime value (<= 16384): blocks of 256 tiles beyond
-// n / 16 are neither loaded nor counted.
-struct ObTileStatsRt { ob_float4 a[2]; };          // block 0 (the first 4096 elements); further blocks are re-read in the combine
-__device__ __forceinline__ void ob_tiles_load_rt(ObTileStatsRt &r, const float *st, int n, int lane)
-{
-    const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)lane * 8);
-    r.a[0] = p[0];
-    r.a[1] = p[1];
-}
-__device__ __forceinline__ void ob_tiles_combine_rt(const ObTileStatsRt &r, const float *st, int n, float eps, int lane, float &mean, float &rstd)
-{
-    const int ntiles = n >> 4;
-    float s = 0.f;
-    for (int v = 0; v * 256 < ntiles; ++v) {               // uniform trip count; 1 for vectors up to 4096
-        ob_float4 a0 = r.a[0], a1 = r.a[1];
-        if (v) { const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8); a0 = p[0]; a1 = p[1]; }
-        const int t = (v * 64 + lane) * 4;
-        s += (t < ntiles ? a0[0] : 0.f) + (t + 1 < ntiles ? a0[2] : 0.f) + (t + 2 < ntiles ? a1[0] : 0.f) + (t + 3 < ntiles ? a1[2] : 0.f);
-    }
-    s = ob_wave_sum(s);
-    const float inv_n = __builtin_amdgcn_rcpf((float)n);
-    mean = s * inv_n;
-    float m2 = 0.f;
-    for (int v = 0; v * 256 < ntiles; ++v) {
-        ob_float4 a0 = r.a[0], a1 = r.a[1];
-        if (v) { const ob_float4 *p = reinterpret_cast<const ob_float4 *>(st + (size_t)(v * 64 + lane) * 8); a0 = p[0]; a1 = p[1]; }
-        const int t = (v * 64 + lane) * 4;
-        const float sv[4] = {a0[0], a0[2], a1[0], a1[2]}, qv[4] = {a0[1], a0[3], a1[1], a1[3]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = __builtin_fmaf(sv[i], 0.0625f, -mean);
-            m2 += t + i < ntiles ? __builtin_fmaf(16.0f * d, d, qv[i]) : 0.f;
-        }
-    }
-    m2 = ob_wave_sum(m2);
-    rstd = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_n, 0.f) + eps);
-}
+// (ObTileStatsRt / ob_tiles_load_rt / ob_tiles_combine_rt: ob_rowstats.h)
 
 // sum over the 16 lanes of a DPP row, in every lane of the row
 __device__ __forceinline__ float ob_row16_sum(float v)

@@ -18,6 +18,7 @@
 // LlamaFlashAttention2 switch (:588).  Bytes: 2 * 2 * D * L per (row, head): HBM-bound (8 loads of 16 B per thread in flight).
 #pragma once
 #include "ob_common.h"
+#include "ob_rowstats.h"
 
 struct ObFdecArgs {
     const _Float16 *q;            // [rows, H, D] post-RoPE queries (token-major)
@@ -31,6 +32,17 @@ struct ObFdecArgs {
     int *counter;                 // [rows][H] arrival tickets, zero between launches
     int H, Hkv, D, max_len, n_slots, chunk, nsplit;
     float inv_sqrt_d;
+    // FUSED form (the decode engines' key-block route without the separate rope / append launch): the query is formed HERE from the
+    // pre-LayerNorm projection rows -- LayerNorm from the producer's per-tile partials (bitnet.py:118), optional bias (:119-120),
+    // RoPE at the row's position (modeling_bitllama.py:175-181, every op rounded to fp16) -- by every (head, row, split) workgroup for
+    // its own head (128 elements); the workgroup of the LAST live split also forms the new key and value, uses them for position
+    // `pos` from LDS and -- one workgroup per kv head -- appends them to the cache (the arithmetic of ob_dec_attn_kernel's PST form).
+    const _Float16 *u_q, *u_k, *u_v;     // [rows, H*D], [rows, Hkv*D] x 2
+    const float *st_q, *st_k, *st_v;     // tile partials per row: ob_tile_stats_floats(n) floats each (ob_decode.h)
+    const _Float16 *b_q, *b_k, *b_v;     // optional biases
+    const _Float16 *cos, *sin;           // [max_pos, D]
+    _Float16 *kw, *vw;                   // the caches again, writable
+    float ln_eps;
 };
 
 __device__ __forceinline__ float ob_fd_row_sum(float v)     // sum over the 16 lanes of a DPP row, in every lane
@@ -59,11 +71,12 @@ __device__ __forceinline__ float ob_fd_rows_max(float v)
 #define OB_FD_THREADS 256
 #define OB_FD_PG 16               // position groups per workgroup
 
-template <int NI>                 // keys per thread in flight (16 * NI positions per sweep of the workgroup)
+template <int NI, bool FUSED = false>   // NI: keys per thread in flight (16 * NI positions per sweep of the workgroup)
 __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float sm[4 * 128 + 16];      // po[4 waves][128] | red[16] (ONE LDS object)
+    __shared__ __attribute__((aligned(16))) float sm[4 * 128 + 16 + (FUSED ? 3 * 64 : 0)];      // po[4 waves][128] | red[16] | q, k, v (ONE LDS object)
     float *po = sm, *red = sm + 4 * 128;
+    _Float16 *q_s = reinterpret_cast<_Float16 *>(sm + 4 * 128 + 16), *k_s = q_s + 128, *v_s = k_s + 128;
     const int head = blockIdx.x, row = blockIdx.y, split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ds = tid & 15, pg = tid >> 4;
@@ -81,19 +94,6 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
     const int dcl = dok ? 8 * ds : 0;
     const _Float16 *kb = A.k + (((int64_t)slot * A.Hkv + kvh) * A.max_len) * D + dcl;
     const _Float16 *vb = A.v + (((int64_t)slot * A.Hkv + kvh) * A.max_len) * D + dcl;
-    ob_half8 q8 = *reinterpret_cast<const ob_half8 *>(A.q + ((int64_t)row * H + head) * D + dcl);
-    if (!dok) q8 = (ob_half8)(_Float16)0;
-    auto dot8 = [](const ob_half8 a, const ob_half8 b) {
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const ob_half2 x = {a[2 * e], a[2 * e + 1]}, y = {b[2 * e], b[2 * e + 1]};
-            acc = __builtin_amdgcn_fdot2(x, y, acc, false);
-        }
-        return acc;
-    };
-    float m = -INFINITY, l = 0.f;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the next sweep's rows are requested before the current sweep's arithmetic (two register sets): a split of several sweeps
     // keeps 2 * NI loads per thread in flight instead of draining between sweeps
     ob_half8 k8[NI], v8[NI], kn[NI], vn[NI];
@@ -105,7 +105,67 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
             vd[i] = __builtin_nontemporal_load(reinterpret_cast<const ob_half8 *>(vb + off));
         }
     };
-    fetch(k8, v8, p_lo);
+    fetch(k8, v8, p_lo);                                                             // in flight under the query's formation (FUSED)
+    ob_half8 q8, kn8 = (ob_half8)(_Float16)0, vn8 = (ob_half8)(_Float16)0;
+    const bool own_new = FUSED && split == nlive - 1;                                // (uniform) this split holds position `pos`
+    if (FUSED) {
+        // roles: wave 0 forms q, waves 1 / 2 (last live split only) k / v -- each combines ITS vector's tile partials; a lane holds
+        // both elements of a rotate_half pair (d, d + D / 2)
+        const int half = D >> 1, NQ = H * D, NK = A.Hkv * D;
+        const int role = wave;
+        if (role == 0 || (own_new && role < 3)) {                                    // (wave-uniform)
+            const int n_r = role == 0 ? NQ : NK;
+            const size_t sf = (size_t)((n_r + 4095) >> 12) * 512;
+            const float *st_r = (role == 0 ? A.st_q : (role == 1 ? A.st_k : A.st_v)) + (size_t)row * sf;
+            const _Float16 *ub = role == 0 ? A.u_q + (int64_t)row * NQ + head * D : (role == 1 ? A.u_k : A.u_v) + (int64_t)row * NK + kvh * D;
+            const int d0 = min(lane, half - 1), d1 = d0 + half;
+            ObTileStatsRt tr;
+            ob_tiles_load_rt(tr, st_r, n_r, lane);
+            const _Float16 ur0 = ub[d0], ur1 = ub[d1];
+            _Float16 br0 = (_Float16)0, br1 = (_Float16)0;
+            if (A.b_q) {                                                             // (uniform)
+                const _Float16 *bb = role == 0 ? A.b_q + head * D : (role == 1 ? A.b_k : A.b_v) + kvh * D;
+                br0 = bb[d0]; br1 = bb[d1];
+            }
+            const _Float16 rc0 = A.cos[(int64_t)pos * D + d0], rs0 = A.sin[(int64_t)pos * D + d0];
+            const _Float16 rc1 = A.cos[(int64_t)pos * D + d1], rs1 = A.sin[(int64_t)pos * D + d1];
+            float mr, rr;
+            ob_tiles_combine_rt(tr, st_r, n_r, A.ln_eps, lane, mr, rr);
+            float y0 = ob_ln_apply((float)ur0, mr, rr), y1 = ob_ln_apply((float)ur1, mr, rr);
+            if (A.b_q) { y0 = ob_round_h(y0 + (float)br0); y1 = ob_round_h(y1 + (float)br1); }
+            float e0 = y0, e1 = y1;
+            if (role < 2) {                      // apply_rotary_pos_emb: x * cos + rotate_half(x) * sin, each op rounded to fp16
+                e0 = ob_round_h(ob_round_h(y0 * (float)rc0) + ob_round_h(-y1 * (float)rs0));
+                e1 = ob_round_h(ob_round_h(y1 * (float)rc1) + ob_round_h(y0 * (float)rs1));
+            }
+            _Float16 *dst = role == 0 ? q_s : (role == 1 ? k_s : v_s);
+            if (lane < half) {
+                dst[d0] = (_Float16)e0; dst[d1] = (_Float16)e1;
+                if (role > 0 && head % (H / A.Hkv) == 0) {                            // one workgroup per kv head appends to the cache
+                    _Float16 *cr = (role == 1 ? A.kw : A.vw) + (((int64_t)slot * A.Hkv + kvh) * A.max_len + pos) * D;
+                    cr[d0] = (_Float16)e0; cr[d1] = (_Float16)e1;
+                }
+            }
+            for (int d = D + lane; d < 128; d += 64) dst[d] = (_Float16)0;            // zero padding beyond the head dimension
+        }
+        __syncthreads();
+        q8 = *reinterpret_cast<const ob_half8 *>(q_s + 8 * ds);
+        if (own_new) { kn8 = *reinterpret_cast<const ob_half8 *>(k_s + 8 * ds); vn8 = *reinterpret_cast<const ob_half8 *>(v_s + 8 * ds); }
+    } else {
+        q8 = *reinterpret_cast<const ob_half8 *>(A.q + ((int64_t)row * H + head) * D + dcl);
+        if (!dok) q8 = (ob_half8)(_Float16)0;
+    }
+    auto dot8 = [](const ob_half8 a, const ob_half8 b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const ob_half2 x = {a[2 * e], a[2 * e + 1]}, y = {b[2 * e], b[2 * e + 1]};
+            acc = __builtin_amdgcn_fdot2(x, y, acc, false);
+        }
+        return acc;
+    };
+    float m = -INFINITY, l = 0.f;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int base = p_lo; base < p_hi; base += OB_FD_PG * NI) {
         const bool more = base + OB_FD_PG * NI < p_hi;                               // (uniform)
         if (more) fetch(kn, vn, base + OB_FD_PG * NI);
@@ -114,6 +174,9 @@ __global__ __launch_bounds__(OB_FD_THREADS) void ob_fdec_kernel(const ObFdecArgs
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int p = base + pg + OB_FD_PG * i;
+            // FUSED: the new token's key / value come from LDS, not from the cache (whose row `pos` another workgroup writes); the
+            // masked tail of the last sweep (p > pos: clamped reads of that same row) takes them too -- finite values, weight 0
+            if (FUSED && p >= pos) { k8[i] = kn8; v8[i] = vn8; }
             const float dot = ob_fd_row_sum(dot8(q8, k8[i]));
             const float sv = ob_round_h(ob_round_h(dot) * A.inv_sqrt_d);         // :546, fp16 matmul output, / sqrt(D) -> fp16
             sc[i] = p < p_hi ? sv : -INFINITY;

@@ -1307,13 +1307,23 @@ static int ob_batched_layers(const onebit_model_t *m, const onebit_batch_state_t
             if ((L.q_bias || L.k_bias || L.v_bias) && !(L.q_bias && L.k_bias && L.v_bias))
                 return ob_fail(ONEBIT_E_ARG, "decode_step_batched: layer %d has some but not all of q_bias / k_bias / v_bias", l);
             const int chunk = st->attn_chunk > 0 ? st->attn_chunk : 256;
-            if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, at.kcache, at.vcache,
-                                                  L.q_bias, L.k_bias, L.v_bias, B, m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, m->ln_eps, s)))
-                return rc;
-            if ((rc = onebit_attention_decode_rows(st->q_rows, at.kcache, at.vcache, st->attn_out, h_o, nullptr, st->pos, B, m->n_heads, m->n_kv_heads, D,
-                                                   B, m->max_len, chunk, st->attn_splits, st->attn_scratch,
-                                                   onebit_attention_decode_scratch_bytes(B, m->n_heads, st->attn_splits), s)))
-                return rc;
+            static const int fuse_env = getenv("OB_FDEC_FUSED") ? atoi(getenv("OB_FDEC_FUSED")) : 1;      // A/B: 0 = rope / append launch + attention
+            const size_t sbytes = onebit_attention_decode_scratch_bytes(B, m->n_heads, st->attn_splits);
+            if (fuse_env && attn_pst && (D & (D - 1)) == 0 && D >= 16) {
+                // the q|k|v GEMM published the rows' LayerNorm partials: the attention launch forms q (k, v in the last split) itself
+                if ((rc = onebit_attention_decode_rows_fused(st->u_q, st->u_k, st->u_v, qs.s[0], qs.s[1], qs.s[2], L.q_bias, L.k_bias, L.v_bias,
+                                                             m->rope_cos, m->rope_sin, at.kcache, at.vcache, st->attn_out, h_o, nullptr, st->pos, B,
+                                                             m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, chunk, st->attn_splits,
+                                                             m->ln_eps, st->attn_scratch, sbytes, s)))
+                    return rc;
+            } else {
+                if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, at.kcache, at.vcache,
+                                                      L.q_bias, L.k_bias, L.v_bias, B, m->n_heads, m->n_kv_heads, D, B, m->max_len, m->max_len, m->ln_eps, s)))
+                    return rc;
+                if ((rc = onebit_attention_decode_rows(st->q_rows, at.kcache, at.vcache, st->attn_out, h_o, nullptr, st->pos, B, m->n_heads, m->n_kv_heads, D,
+                                                       B, m->max_len, chunk, st->attn_splits, st->attn_scratch, sbytes, s)))
+                    return rc;
+            }
         } else {
         if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_batched: max_len %d too large for the one-workgroup attention kernel (set attn_splits)", m->max_len);
         // 4-wave workgroups: twice as many (head, slot) workgroups resident per CU (2.95 -> 2.89 ms per 32-slot step)
@@ -1678,13 +1688,23 @@ extern "C" int onebit_decode_step(const onebit_model_t *m, const onebit_decode_s
         if (rope_cur) at.rope_cur = (const _Float16 *)st->rope_cur;
         at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
         if (keyblock) {
-            if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, L.k_cache, L.v_cache,
-                                                  L.q_bias, L.k_bias, L.v_bias, 1, m->n_heads, m->n_kv_heads, D, 1, m->max_len, m->max_len, m->ln_eps, s)))
-                return rc;
-            if ((rc = onebit_attention_decode_rows(st->q_rows, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads, m->n_kv_heads, D,
-                                                   1, m->max_len, st->attn_chunk, st->attn_splits, st->attn_scratch,
-                                                   onebit_attention_decode_scratch_bytes(1, m->n_heads, st->attn_splits), s)))
-                return rc;
+            static const int fuse_env = getenv("OB_FDEC_FUSED") ? atoi(getenv("OB_FDEC_FUSED")) : 1;      // A/B: 0 = rope / append launch + attention
+            const size_t sbytes = onebit_attention_decode_scratch_bytes(1, m->n_heads, st->attn_splits);
+            if (fuse_env && ts_q && (D & (D - 1)) == 0 && D >= 16) {
+                // the q|k|v GEMV published the vectors' LayerNorm partials: the attention launch forms q (k, v in the last split) itself
+                if ((rc = onebit_attention_decode_rows_fused(st->u_q, st->u_k, st->u_v, ts_q, ts_k, ts_v, L.q_bias, L.k_bias, L.v_bias, m->rope_cos,
+                                                             m->rope_sin, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads,
+                                                             m->n_kv_heads, D, 1, m->max_len, m->max_len, st->attn_chunk, st->attn_splits, m->ln_eps,
+                                                             st->attn_scratch, sbytes, s)))
+                    return rc;
+            } else {
+                if ((rc = onebit_rows_qkv_rope_ragged(st->u_q, st->u_k, st->u_v, m->rope_cos, m->rope_sin, nullptr, st->pos, st->q_rows, L.k_cache, L.v_cache,
+                                                      L.q_bias, L.k_bias, L.v_bias, 1, m->n_heads, m->n_kv_heads, D, 1, m->max_len, m->max_len, m->ln_eps, s)))
+                    return rc;
+                if ((rc = onebit_attention_decode_rows(st->q_rows, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads, m->n_kv_heads, D,
+                                                       1, m->max_len, st->attn_chunk, st->attn_splits, st->attn_scratch, sbytes, s)))
+                    return rc;
+            }
         } else if (st->attn_splits > 1 && st->attn_scratch) {
             const int S = st->attn_splits;
             if (S > 16) return ob_fail(ONEBIT_E_SHAPE, "decode_step: attn_splits %d > 16", S);

@@ -70,12 +70,15 @@ extern "C" size_t onebit_attention_decode_scratch_bytes(int64_t rows, int32_t n_
 }
 
 // `cap_rows` >= rows: the row count the scratch is laid out for (tickets [cap_rows][H] | {max, sum} [cap_rows][H][n_splits][2] |
-// partial outputs [cap_rows][H][n_splits][128]): tickets FIRST, their place depends on (cap_rows, n_heads) only
+// partial outputs [cap_rows][H][n_splits][128]): tickets FIRST, their place depends on (cap_rows, n_heads) only.
+// `fu` (optional): the FUSED form's inputs (ObFdecArgs fields u_q .. ln_eps filled in; q unused).
 static int ob_fdec_launch(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next, const int32_t *row_slot,
                           const int32_t *row_pos, int64_t rows, int64_t cap_rows, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
-                          int64_t n_slots, int64_t max_len, int32_t chunk, int32_t n_splits, void *scratch, hipStream_t stream)
+                          int64_t n_slots, int64_t max_len, int32_t chunk, int32_t n_splits, void *scratch, hipStream_t stream,
+                          const ObFdecArgs *fu = nullptr)
 {
     ObFdecArgs a = {};
+    if (fu) a = *fu;
     a.q = (const _Float16 *)q; a.k = (const _Float16 *)k_cache; a.v = (const _Float16 *)v_cache; a.o = (_Float16 *)o;
     a.h_next = (const _Float16 *)h_next; a.row_slot = row_slot; a.row_pos = row_pos;
     a.H = n_heads; a.Hkv = n_kv_heads; a.D = head_dim; a.max_len = (int)max_len; a.n_slots = (int)n_slots; a.chunk = chunk; a.nsplit = n_splits;
@@ -87,10 +90,58 @@ static int ob_fdec_launch(const void *q, const void *k_cache, const void *v_cach
         a.part_ml = (float *)p; p += ob_align256(rh * n_splits * 2 * 4);
         a.part_o = (float *)p;
     }
+    const dim3 grid((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits);
     // keys per thread in flight: a 128-position multiple sweeps 8 per thread (one round trip per 128 positions), else 4
-    if (chunk % 128 == 0) hipLaunchKernelGGL((ob_fdec_kernel<8>), dim3((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits), dim3(OB_FD_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL((ob_fdec_kernel<4>), dim3((unsigned)n_heads, (unsigned)rows, (unsigned)n_splits), dim3(OB_FD_THREADS), 0, stream, a);
+    if (fu) {
+        if (chunk % 128 == 0) hipLaunchKernelGGL((ob_fdec_kernel<8, true>), grid, dim3(OB_FD_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((ob_fdec_kernel<4, true>), grid, dim3(OB_FD_THREADS), 0, stream, a);
+    } else if (chunk % 128 == 0) hipLaunchKernelGGL((ob_fdec_kernel<8>), grid, dim3(OB_FD_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((ob_fdec_kernel<4>), grid, dim3(OB_FD_THREADS), 0, stream, a);
     return ob_launch_status("attention_decode_rows");
+}
+
+static int ob_fdec_check(const char *fn, int64_t rows, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t n_slots, int64_t max_len,
+                         int32_t chunk, int32_t n_splits, const void *scratch, size_t scratch_bytes)
+{
+    if (rows < 0 || n_heads <= 0 || n_kv_heads <= 0 || n_slots <= 0 || max_len <= 0) return ob_fail(ONEBIT_E_ARG, "%s: bad size", fn);
+    if (head_dim < 8 || head_dim % 8 != 0 || head_dim > 128 || n_heads % n_kv_heads != 0)
+        return ob_fail(ONEBIT_E_SHAPE, "%s: head_dim %d (multiple of 8, <= 128), heads %d / %d", fn, head_dim, n_heads, n_kv_heads);
+    if (chunk < 64 || chunk % 64 != 0 || n_splits < 1 || n_splits > 65535)
+        return ob_fail(ONEBIT_E_SHAPE, "%s: chunk %d (a multiple of 64) x %d splits", fn, chunk, n_splits);
+    if (rows > 65535 || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "%s: dimension too large", fn);
+    const size_t need = onebit_attention_decode_scratch_bytes(rows, n_heads, n_splits);
+    if (rows > 0 && need && (!scratch || scratch_bytes < need || !ob_aligned(scratch, 16)))
+        return ob_fail(ONEBIT_E_WSPACE, "%s: needs %zu bytes of zero-initialised, 16-byte aligned scratch", fn, need);
+    return 0;
+}
+
+// The FUSED form: q (and, in the last live split, k / v + the cache append) formed inside the attention launch from the pre-LayerNorm
+// projection rows and the producer's tile partials -- what the decode engines call when those partials exist (one launch less per layer).
+extern "C" int onebit_attention_decode_rows_fused(const void *u_q, const void *u_k, const void *u_v, const float *st_q, const float *st_k,
+                                                  const float *st_v, const void *q_bias, const void *k_bias, const void *v_bias,
+                                                  const void *cos, const void *sin, void *k_cache, void *v_cache, void *o, const void *h_next,
+                                                  const int32_t *row_slot, const int32_t *row_pos, int64_t rows, int32_t n_heads,
+                                                  int32_t n_kv_heads, int32_t head_dim, int64_t n_slots, int64_t max_len, int64_t max_pos,
+                                                  int32_t chunk, int32_t n_splits, float ln_eps, void *scratch, size_t scratch_bytes, void *stream)
+{
+    const int rc = ob_fdec_check("attention_decode_rows_fused", rows, n_heads, n_kv_heads, head_dim, n_slots, max_len, chunk, n_splits, scratch, scratch_bytes);
+    if (rc) return rc;
+    if (head_dim < 16 || (head_dim & (head_dim - 1)) != 0) return ob_fail(ONEBIT_E_SHAPE, "attention_decode_rows_fused: head_dim %d must be a power of two >= 16", head_dim);
+    if (((int64_t)n_heads * head_dim) % 16 != 0 || ((int64_t)n_kv_heads * head_dim) % 16 != 0 || (int64_t)n_heads * head_dim > 16384)
+        return ob_fail(ONEBIT_E_SHAPE, "attention_decode_rows_fused: the tile partials need whole 16-row tiles and rows of at most 16384 elements");
+    if (max_len > max_pos) return ob_fail(ONEBIT_E_SHAPE, "attention_decode_rows_fused: cache rows (%lld) beyond the rope tables (%lld)", (long long)max_len, (long long)max_pos);
+    if (rows == 0) return 0;
+    if (!u_q || !u_k || !u_v || !st_q || !st_k || !st_v || !cos || !sin || !k_cache || !v_cache || !o || !row_pos)
+        return ob_fail(ONEBIT_E_ARG, "attention_decode_rows_fused: null pointer");
+    if ((q_bias || k_bias || v_bias) && !(q_bias && k_bias && v_bias)) return ob_fail(ONEBIT_E_ARG, "attention_decode_rows_fused: some but not all biases");
+    if (!ob_aligned(k_cache, 16) || !ob_aligned(v_cache, 16) || !ob_aligned(st_q, 16) || !ob_aligned(st_k, 16) || !ob_aligned(st_v, 16))
+        return ob_fail(ONEBIT_E_ALIGN, "attention_decode_rows_fused: caches and tile partials must be 16-byte aligned");
+    ObFdecArgs f = {};
+    f.u_q = (const _Float16 *)u_q; f.u_k = (const _Float16 *)u_k; f.u_v = (const _Float16 *)u_v; f.st_q = st_q; f.st_k = st_k; f.st_v = st_v;
+    f.b_q = (const _Float16 *)q_bias; f.b_k = (const _Float16 *)k_bias; f.b_v = (const _Float16 *)v_bias;
+    f.cos = (const _Float16 *)cos; f.sin = (const _Float16 *)sin; f.kw = (_Float16 *)k_cache; f.vw = (_Float16 *)v_cache; f.ln_eps = ln_eps;
+    return ob_fdec_launch(nullptr, k_cache, v_cache, o, h_next, row_slot, row_pos, rows, rows, n_heads, n_kv_heads, head_dim, n_slots, max_len, chunk,
+                          n_splits, scratch, (hipStream_t)stream, &f);
 }
 
 extern "C" int onebit_attention_decode_rows(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next,
@@ -98,19 +149,12 @@ extern "C" int onebit_attention_decode_rows(const void *q, const void *k_cache, 
                                             int32_t n_kv_heads, int32_t head_dim, int64_t n_slots, int64_t max_len, int32_t chunk,
                                             int32_t n_splits, void *scratch, size_t scratch_bytes, void *stream)
 {
-    if (rows < 0 || n_heads <= 0 || n_kv_heads <= 0 || n_slots <= 0 || max_len <= 0) return ob_fail(ONEBIT_E_ARG, "attention_decode_rows: bad size");
-    if (head_dim < 8 || head_dim % 8 != 0 || head_dim > 128 || n_heads % n_kv_heads != 0)
-        return ob_fail(ONEBIT_E_SHAPE, "attention_decode_rows: head_dim %d (multiple of 8, <= 128), heads %d / %d", head_dim, n_heads, n_kv_heads);
-    if (chunk < 64 || chunk % 64 != 0 || n_splits < 1 || n_splits > 65535)
-        return ob_fail(ONEBIT_E_SHAPE, "attention_decode_rows: chunk %d (a multiple of 64) x %d splits", chunk, n_splits);
+    const int rc = ob_fdec_check("attention_decode_rows", rows, n_heads, n_kv_heads, head_dim, n_slots, max_len, chunk, n_splits, scratch, scratch_bytes);
+    if (rc) return rc;
     if (rows == 0) return 0;
     if (!q || !k_cache || !v_cache || !o || !row_pos) return ob_fail(ONEBIT_E_ARG, "attention_decode_rows: null pointer");
     if (!ob_aligned(q, 16) || !ob_aligned(k_cache, 16) || !ob_aligned(v_cache, 16) || !ob_aligned(o, 2))
         return ob_fail(ONEBIT_E_ALIGN, "attention_decode_rows: q / k / v must be 16-byte aligned");
-    if (rows > 65535 || max_len > 0x7fffffffLL) return ob_fail(ONEBIT_E_ARG, "attention_decode_rows: dimension too large");
-    const size_t need = onebit_attention_decode_scratch_bytes(rows, n_heads, n_splits);
-    if (need && (!scratch || scratch_bytes < need || !ob_aligned(scratch, 16)))
-        return ob_fail(ONEBIT_E_WSPACE, "attention_decode_rows: needs %zu bytes of zero-initialised, 16-byte aligned scratch", need);
     return ob_fdec_launch(q, k_cache, v_cache, o, h_next, row_slot, row_pos, rows, rows, n_heads, n_kv_heads, head_dim, n_slots, max_len, chunk,
                           n_splits, scratch, (hipStream_t)stream);
 }

@@ -198,9 +198,10 @@ def _model_struct(model: OneBitLlamaForCausalLM, caches, max_len: int, krange=No
 
 class DecodeEngine:
     def __init__(self, model: OneBitLlamaForCausalLM, max_len: int, use_graph: bool = True,
-                 long_context_from: int = 384, attn_splits: int = 8, long_attention: str = "keyblock", attn_chunk: int = 128):
-        """``long_context_from``: position from which a step uses a split-KV attention graph (two launches per layer over
-        head x split); below it one workgroup per head is faster.  0 disables.
+                 long_context_from: int = 160, attn_splits: int = 8, long_attention: str = "keyblock", attn_chunk: int = 128):
+        """``long_context_from``: position from which a step uses a split-KV attention graph; below it one workgroup per head
+        with the first 128 positions' scores in registers is faster (measured crossover on 7B: 0.947 vs 0.963 ms / token at 132-164
+        cached tokens, 1.184 vs 0.971 at 260-292: tools/ctx_probe.py).  0 disables.
         ``long_attention``: "keyblock" (round 6, default: LayerNorm + RoPE + cache append in one launch, then
         ``onebit_attention_decode_rows`` -- ``attn_chunk`` positions per workgroup, K and V read once, last-arriver combine; one
         HIP graph per power-of-two split count, chosen per step by the host-known position) or "pair" (round 2: scores kernel +

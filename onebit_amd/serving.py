@@ -168,11 +168,11 @@ class Scheduler:
 class ContinuousBatcher:
     def __init__(self, model: OneBitLlamaForCausalLM, max_batch: int = 32, max_len: int = 256,
                  max_step_tokens: Optional[int] = None, use_graph: bool = True, native: bool = True,
-                 prefill_chunk: Optional[int] = None, max_burst: int = 1, long_context_from: int = 256, attn_chunk: int = 512):
+                 prefill_chunk: Optional[int] = None, max_burst: int = 1, long_context_from: int = 128, attn_chunk: int = 512):
         """``long_context_from``: a decode-only step whose longest context exceeds it replays the graph of the KEY-BLOCK attention
         (``onebit_decode_step_batched`` with ``attn_splits``: ``attn_chunk`` positions per workgroup, one graph per power-of-two
-        split count) instead of the one-workgroup-per-(head, slot) form -- measured crossover at 32 slots on 7B ~256 positions
-        (tools/serve_ctx_probe.py), and the only form once 4 * max_len + 5.4 KB of scores no longer fit the LDS."""
+        split count) instead of the one-workgroup-per-(head, slot) form -- measured at 32 slots on 7B: equal at 128 cached
+        tokens (2.37 ms), 2.64 vs 2.81 ms at 256, 3.23 vs 3.61 at 512 (tools/serve_ctx_probe.py), and the only form once 4 * max_len + 5.4 KB of scores no longer fit the LDS."""
         p = model.lm_head.weight
         if not p.is_cuda:
             raise RuntimeError("ContinuousBatcher needs the model on a ROCm GPU (no CPU fallback)")

@@ -334,3 +334,68 @@ def test_engines_take_the_keyblock_graphs_at_long_contexts():
     for rid, (pp, m) in zip(rids, reqs):
         r = model.generate(torch.tensor([pp], device=dev), m)[0, len(pp):].tolist()
         assert out[rid] == r or _near_tie(model, pp, r, out[rid], dev), rid
+
+
+def _tile_partials(u):
+    """Per-16-row-tile LayerNorm partials {sum, sum of squared deviations from the tile mean} of the rows of u [rows, n] in the layout
+    the decode kernels publish them (ceil(n / 4096) * 512 floats per row, tile t at [2t], [2t + 1])."""
+    rows, n = u.shape
+    t = u.float().view(rows, n // 16, 16)
+    sm = t.sum(-1)
+    m2 = ((t - sm[..., None] / 16.0) ** 2).sum(-1)
+    st = torch.zeros(rows, ((n + 4095) // 4096) * 512, dtype=torch.float32, device=u.device)
+    st[:, 0:2 * (n // 16):2] = sm
+    st[:, 1:2 * (n // 16):2] = m2
+    return st.contiguous()
+
+
+@pytest.mark.parametrize("H,Hkv,D,chunk,bias", [(8, 8, 64, 64, False), (8, 2, 128, 128, True), (32, 32, 128, 128, False)])
+def test_fused_decode_rows_equals_rope_launch_plus_attention(H, Hkv, D, chunk, bias):
+    """onebit_attention_decode_rows_fused (query formed inside the attention launch from the pre-LayerNorm rows + tile partials, new key /
+    value from LDS, cache append by the last split's workgroup) against onebit_rows_qkv_rope_ragged + onebit_attention_decode_rows on the
+    same inputs: outputs within fp16 rounding, the appended cache rows within an fp16 ulp (statistics from partials vs from the rows)."""
+    L, lib = _lib()
+    dev = torch.device(DEV)
+    g = torch.Generator(device="cpu").manual_seed(3 * H + D)
+    max_len, slots = 400, 7
+    ctx = [1, chunk, chunk + 1, 2 * chunk + 5, 399, 77]
+    rows = len(ctx) + 1
+    NQ, NK = H * D, Hkv * D
+    uq, uk, uv = [(torch.randn(rows, n, generator=g) * 2 + 0.3).half().to(dev) for n in (NQ, NK, NK)]
+    bq, bk, bv = [(torch.randn(n, generator=g) * 0.3).half().to(dev) if bias else None for n in (NQ, NK, NK)]
+    bp = lambda b: None if b is None else b.data_ptr()
+    cos, sin = _rope_tables(D, max_len, dev)
+    base_k = (torch.randn(slots, Hkv, max_len, D, generator=g) * 0.7).half().to(dev)
+    base_v = torch.randn(slots, Hkv, max_len, D, generator=g).half().to(dev)
+    row_slot = torch.tensor([3, 0, 6, 1, 5, 2, 4], dtype=torch.int32, device=dev)
+    row_pos = torch.tensor([c - 1 for c in ctx] + [-1], dtype=torch.int32, device=dev)
+    hn = (0.5 + torch.rand(NQ, generator=g)).half().to(dev)
+    nsplit = -(-max_len // chunk)
+    scratch = torch.zeros(max(int(lib.onebit_attention_decode_scratch_bytes(rows, H, nsplit)), 16), dtype=torch.uint8, device=dev)
+    # reference route: rope / append launch, then the attention
+    k0, v0 = base_k.clone(), base_v.clone()
+    q = torch.zeros(rows, NQ, dtype=torch.float16, device=dev)
+    o0 = torch.zeros(rows, NQ, dtype=torch.float16, device=dev)
+    L.check(lib.onebit_rows_qkv_rope_ragged(uq.data_ptr(), uk.data_ptr(), uv.data_ptr(), cos.data_ptr(), sin.data_ptr(), row_slot.data_ptr(),
+                                            row_pos.data_ptr(), q.data_ptr(), k0.data_ptr(), v0.data_ptr(), bp(bq), bp(bk), bp(bv), rows, H, Hkv, D,
+                                            slots, max_len, max_len, 1e-5, _sp()), "rope")
+    L.check(lib.onebit_attention_decode_rows(q.data_ptr(), k0.data_ptr(), v0.data_ptr(), o0.data_ptr(), hn.data_ptr(), row_slot.data_ptr(),
+                                             row_pos.data_ptr(), rows, H, Hkv, D, slots, max_len, chunk, nsplit, scratch.data_ptr(), scratch.numel(), _sp()), "rows")
+    # fused route
+    k1, v1 = base_k.clone(), base_v.clone()
+    o1 = torch.zeros(rows, NQ, dtype=torch.float16, device=dev)
+    sq, sk, sv = _tile_partials(uq), _tile_partials(uk), _tile_partials(uv)
+    L.check(lib.onebit_attention_decode_rows_fused(uq.data_ptr(), uk.data_ptr(), uv.data_ptr(), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), bp(bq), bp(bk),
+                                                   bp(bv), cos.data_ptr(), sin.data_ptr(), k1.data_ptr(), v1.data_ptr(), o1.data_ptr(), hn.data_ptr(),
+                                                   row_slot.data_ptr(), row_pos.data_ptr(), rows, H, Hkv, D, slots, max_len, max_len, chunk, nsplit, 1e-5,
+                                                   scratch.data_ptr(), scratch.numel(), _sp()), "fused")
+    torch.cuda.synchronize()
+    live = slice(0, rows - 1)
+    assert float(o1[-1].abs().max()) == 0.0                                        # idle row untouched
+    scale = float(o0[live].float().abs().max())
+    assert float((o0[live].float() - o1[live].float()).abs().max()) <= 3e-3 * scale
+    assert float((k0.float() - k1.float()).abs().max()) <= 2.0 ** -9 * float(k0.abs().max())
+    assert float((v0.float() - v1.float()).abs().max()) <= 2.0 ** -9 * float(v0.abs().max())
+    assert float((k0 != k1).float().mean()) < 0.01
+    changed = (k1 != base_k).any(-1).sum().item()                                   # exactly one row per (live request, kv head) was appended
+    assert changed == (rows - 1) * Hkv
