@@ -1545,6 +1545,37 @@ int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s)
     return ob_launch_status("rows_norm");
 }
 
+int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
+{
+    static const int env = getenv("OB_GEMM3_GROUPED") ? atoi(getenv("OB_GEMM3_GROUPED")) : 1;       // A/B: 0 = one launch per projection
+    if (!env || np < 2 || np > 3) return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: 2..3 projections");
+    const int64_t K = ps[0]->K, ldw = ps[0]->ldw_bytes;
+    if (T < 192 || K % (4 * OB_G2_K) != 0 || T * K * 2 >= ((int64_t)1 << 32) || ldw % 16 != 0)
+        return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: shape not eligible");
+    ObG3Group G = {};
+    const int nbt = (int)((T + 127) / 128);
+    int64_t tiles = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int j = i < np ? i : np - 1;
+        const onebit_proj_t &p = *ps[j];
+        if (i < np) {
+            if (!p.weight || !p.weight_scale || !us[i] || !as[i] || p.K != K || p.ldw_bytes != ldw || p.N % 4 != 0 || p.N * (K / 8) >= ((int64_t)1 << 32) ||
+                p.N * ldw >= ((int64_t)1 << 32) || !ob_aligned(p.weight, 16) || !ob_aligned(as[i], 16) || !ob_aligned(us[i], 16) || !ob_aligned(p.weight_scale, 8))
+                return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: projection %d not eligible", i);
+            G.nbn[i] = (int)((p.N + OB_G2_N - 1) / OB_G2_N);
+            tiles += (int64_t)G.nbn[i] * nbt;
+        } else G.nbn[i] = G.nbn[j];
+        G.W[i] = (const uint32_t *)p.weight; G.a[i] = (const _Float16 *)as[j]; G.g[i] = (const _Float16 *)p.weight_scale; G.u[i] = (_Float16 *)us[j];
+        G.N[i] = (int)p.N; G.tile_end[i] = (int)tiles;
+    }
+    if (3 * tiles < 2 * (int64_t)ob_cu_count() || tiles > 0x3fffffff) return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: grid too small / large");
+    G.ldw_words = ldw / 4; G.lda = K; G.T = (int)T; G.K = (int)K;
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_gemm3g_f16_kernel<1>, attr_set, OB_G3_LDS_W(1));
+    hipLaunchKernelGGL((ob_gemm3g_f16_kernel<1>), dim3((unsigned)tiles), dim3(256), OB_G3_LDS_W(1), s, G);
+    return ob_launch_status("gemm3_grouped");
+}
+
 int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
 {
     if (np < 1 || np > 3) return ob_fail(ONEBIT_E_ARG, "sk3_multi: 1..3 projections");

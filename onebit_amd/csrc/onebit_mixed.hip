@@ -263,6 +263,10 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
             const void *av[3] = {as[0], as[np > 1 ? 1 : 0], as[np > 2 ? 2 : 0]};
             if (ob_sk3_multi(ps, us, av, np, T, s) == 0) return 0;
         }
+        if (prescaled && T >= 192) {             // one grouped launch of the LDS-DMA GEMM: no partly filled last round per projection
+            const void *av[3] = {as[0], as[np > 1 ? 1 : 0], as[np > 2 ? 2 : 0]};
+            if (ob_gemm3_grouped(ps, us, av, np, T, s) == 0) return 0;
+        }
         for (int i = 0; i < np; ++i) {
             const int rc2 = gemm(*ps[i], as[i], prescaled, us[i]);
             if (rc2) return rc2;
