@@ -401,6 +401,14 @@ typedef struct onebit_kshard_state {
 int onebit_decode_step_ksharded(const onebit_model_t *model, const onebit_kshard_state_t *state, int32_t layer,
                                 int32_t segment, void *stream);
 
+/* ABI 9: up to three projections that share their token rows' count T and in_features K (q | k | v, gate | up of a decoder layer), each on
+ * ITS OWN pre-scaled rows a[i] = fp16(x * input_factor_i) [T, K] (onebit_rows_res_ln_rms with h_next), in ONE launch:
+ * u[i] [T, N_i] = fp16(fp16(W_i . a_i) * g_i), the pre-LayerNorm output (ONEBIT_FLAG_SKIP_LN | ONEBIT_FLAG_PRESCALED semantics of
+ * onebit_linear_forward, bit-identical to it).  One launch instead of three keeps the workgroup rounds full (T = 2048, 7B: three
+ * launches of 256 tiles each on 512 workgroup slots vs one of 768).  2 <= T <= 64: the LDS-DMA skinny GEMM; larger T: the LDS-DMA
+ * GEMM.  Returns ONEBIT_E_SHAPE when the group is not eligible (the caller then issues one onebit_linear_forward per projection). */
+int onebit_linear_group_prescaled(const onebit_proj_t *projs, void *const *u, const void *const *a, int32_t n_proj, int64_t T, void *stream);
+
 /* ---- ragged token rows: several sequences in one call (continuous batching, BASELINE config 5; ABI 9) -----------------
  * The reference runs one rectangular batch per forward (modeling_bitllama.py:1275-1330); a continuous-batching step instead
  * concatenates the token rows of all scheduled requests: item i = rows [row0, row0 + n) of the request whose KV cache is slot

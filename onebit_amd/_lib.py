@@ -46,6 +46,7 @@ SYMBOLS = {
     "onebit_rows_qkv_rope_stats": (_int, [_vp] * 9 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_rows_qkv_rope": (_int, [_vp] * 8 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, ctypes.c_uint, _vp]),
     "onebit_attention_prefill": (_int, [_vp] * 5 + [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _vp]),
+    "onebit_linear_group_prescaled": (_int, [_vp, _vp, _vp, ctypes.c_int32, _i64, _vp]),
     "onebit_rows_res_ln_rms_bias": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _i64, _i64, _f, _f, _vp]),
     "onebit_rows_qkv_rope_ragged": (_int, [_vp] * 13 + [_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "onebit_attention_ragged": (_int, [_vp] * 6 + [ctypes.c_int32] * 4 + [_i64, _i64, _vp]),

@@ -16,6 +16,17 @@
 #include "ob_flash.h"
 #include "ob_fdec.h"
 
+// ------------------------------------------------------------------------------------------------ grouped projections --
+extern "C" int onebit_linear_group_prescaled(const onebit_proj_t *projs, void *const *u, const void *const *a, int32_t n_proj, int64_t T, void *stream)
+{
+    if (!projs || !u || !a || n_proj < 1 || n_proj > 3 || T < 0) return ob_fail(ONEBIT_E_ARG, "linear_group_prescaled: bad arguments");
+    if (T == 0) return 0;
+    const onebit_proj_t *ps[3] = {&projs[0], &projs[n_proj > 1 ? 1 : 0], &projs[n_proj > 2 ? 2 : 0]};
+    if (T >= 2 && T <= 64) return ob_sk3_multi(ps, u, a, n_proj, T, (hipStream_t)stream);
+    if (n_proj < 2) return ob_fail(ONEBIT_E_SHAPE, "linear_group_prescaled: one projection at T > 64: call onebit_linear_forward");
+    return ob_gemm3_grouped(ps, u, a, n_proj, T, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------ ragged prefill attention --
 extern "C" int onebit_attention_ragged(const void *q, const void *k_cache, const void *v_cache, void *o, const void *h_next,
                                        const onebit_seg_t *segs, int32_t n_seg, int32_t n_heads, int32_t n_kv_heads,

@@ -321,6 +321,25 @@ class OneBitLlamaForCausalLM(nn.Module):
             # (a projection's bias -- q / k / v of a checkpoint with config.attention_bias -- joins its LayerNorm in the rope kernel)
             return p.pre_layernorm_bias_deferred(a, prescaled=True) if a is not None else p.pre_layernorm_bias_deferred(x)
 
+        def proj_group(ps, x, xs_):
+            """The pre-LayerNorm outputs of projections that share their input: ONE grouped launch on the producer-scaled rows
+            (onebit_linear_group_prescaled) when the group is eligible, else one call each."""
+            if xs_ is not None and len(ps) > 1:
+                from .engine import _Proj, _proj
+                try:
+                    arr = (_Proj * len(ps))(*[_proj(p, allow_bias=True) for p in ps])
+                except ValueError:                      # shapes the fused structs do not describe: one call per projection
+                    arr = None
+                if arr is not None:
+                    us = [torch.empty((T, p.out_features), dtype=h.dtype, device=h.device) for p in ps]
+                    up = (ctypes.c_void_p * 3)(*[u_.data_ptr() for u_ in us])
+                    ap = (ctypes.c_void_p * 3)(*[a_.data_ptr() for a_ in xs_])
+                    with torch.cuda.device(h.device):
+                        rc = lib.onebit_linear_group_prescaled(ctypes.cast(arr, ctypes.c_void_p), up, ap, len(ps), T, sp)
+                    if rc == 0:
+                        return us
+            return [proj(p, x, None if xs_ is None else a_) for p, a_ in zip(ps, xs_ if xs_ is not None else [None] * len(ps))]
+
         row_arrays = None          # (slot, position) of every token row: the ragged rope kernel, which takes the q / k / v biases
 
         x, xs = m.layers[0].input_layernorm(h), None
@@ -348,8 +367,7 @@ class OneBitLlamaForCausalLM(nn.Module):
                 # q|k|v LayerNorm + RoPE + head transpose in one pass (onebit_rows_qkv_rope): k, v land in
                 # the cache rows, q in token-major [B, S, heads, D]; then the fused causal attention
                 Hh, Hkv, D = att.num_heads, att.num_key_value_heads, att.head_dim
-                aq, ak, av = xs if xs is not None else (None, None, None)
-                u_q, u_k, u_v = proj(att.q_proj, x, aq), proj(att.k_proj, x, ak), proj(att.v_proj, x, av)
+                u_q, u_k, u_v = proj_group((att.q_proj, att.k_proj, att.v_proj), x, xs)
                 q = torch.empty((B, S, Hh, D), dtype=h.dtype, device=h.device)     # token-major: sdpa returns the same layout
                 kc, vc = kv
                 with torch.cuda.device(h.device):
@@ -383,8 +401,7 @@ class OneBitLlamaForCausalLM(nn.Module):
                 u_o = att.forward(x.view(B, S, H), cos, sin, kv, past, pre_ln_out=True).reshape(T, H)
             mlp = layer.mlp
             h, x, xs = res_ln_rms(h, u_o, layer.post_attention_layernorm.weight, (mlp.gate_proj, mlp.up_proj), bias_prev=att.o_proj.bias)
-            ag, au = xs if xs is not None else (None, None)
-            u_g, u_u = proj(mlp.gate_proj, x, ag), proj(mlp.up_proj, x, au)
+            u_g, u_u = proj_group((mlp.gate_proj, mlp.up_proj), x, xs)
             act = torch.empty_like(u_g)
             down_pres = mlp.down_proj.prescaled_ok(T, h.dtype)
             with torch.cuda.device(h.device):
