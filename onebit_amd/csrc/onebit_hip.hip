@@ -15,6 +15,7 @@
 #include "ob_decode.h"
 #include "ob_gemm.h"
 #include "ob_gemm2.h"
+#include "ob_gemm4.h"
 #include "ob_skinny.h"
 #include "ob_skinny3.h"
 #include "ob_batch.h"
@@ -317,13 +318,23 @@ static bool ob_gemm3_ok(int64_t T, int64_t K, int64_t N)
 
 // The LDS-DMA GEMM in its 8-wave (256 x 256 tile, one workgroup per CU) or 4-wave (256 rows x 128 tokens, two workgroups per
 // CU) form; OB_GEMM3_WT=1 / 2 selects (A/B), default below.
+#ifndef OB_GEMM4_DEFAULT
+#define OB_GEMM4_DEFAULT 0
+#endif
 template <bool PARTIAL>
 static void ob_launch_gemm3(const uint32_t *W, int64_t ldw_words, const _Float16 *a, int64_t lda, const _Float16 *g, _Float16 *u,
                             float *zp, int64_t T, int64_t K, int64_t N, hipStream_t s)
 {
     static const int wt_env = getenv("OB_GEMM3_WT") ? atoi(getenv("OB_GEMM3_WT")) : 1;    // 4-wave form: +3-4 % (1286 -> 1335 TFLOP/s on 4096 -> 11008), bit-identical
+    static const int g4_env = getenv("OB_GEMM4") ? atoi(getenv("OB_GEMM4")) : OB_GEMM4_DEFAULT;   // the 32x32x16-MFMA form of the same tiling (ob_gemm4.h)
     const int nbn = (int)((N + OB_G2_N - 1) / OB_G2_N);
-    if (wt_env == 1) {
+    if (g4_env) {
+        static bool attr_set[OB_MAX_DEVICES] = {};
+        ob_set_max_lds_once(ob_gemm4_f16_kernel<PARTIAL>, attr_set, OB_G4_LDS);
+        const int nbt = (int)((T + 127) / 128);
+        hipLaunchKernelGGL((ob_gemm4_f16_kernel<PARTIAL>), dim3((unsigned)(nbn * nbt)), dim3(256), OB_G4_LDS, s,
+                           W, ldw_words, a, lda, g, u, zp, (int)T, (int)K, (int)N, nbn);
+    } else if (wt_env == 1) {
         static bool attr_set[OB_MAX_DEVICES] = {};
         ob_set_max_lds_once(ob_gemm3_f16_kernel<PARTIAL, 1>, attr_set, OB_G3_LDS_W(1));
         const int nbt = (int)((T + 127) / 128);
@@ -1570,6 +1581,13 @@ int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void
     }
     if (3 * tiles < 2 * (int64_t)ob_cu_count() || tiles > 0x3fffffff) return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: grid too small / large");
     G.ldw_words = ldw / 4; G.lda = K; G.T = (int)T; G.K = (int)K;
+    static const int g4_env = getenv("OB_GEMM4") ? atoi(getenv("OB_GEMM4")) : OB_GEMM4_DEFAULT;
+    if (g4_env) {
+        static bool attr_set4[OB_MAX_DEVICES] = {};
+        ob_set_max_lds_once(ob_gemm4g_f16_kernel, attr_set4, OB_G4_LDS);
+        hipLaunchKernelGGL(ob_gemm4g_f16_kernel, dim3((unsigned)tiles), dim3(256), OB_G4_LDS, s, G);
+        return ob_launch_status("gemm4_grouped");
+    }
     static bool attr_set[OB_MAX_DEVICES] = {};
     ob_set_max_lds_once(ob_gemm3g_f16_kernel<1>, attr_set, OB_G3_LDS_W(1));
     hipLaunchKernelGGL((ob_gemm3g_f16_kernel<1>), dim3((unsigned)tiles), dim3(256), OB_G3_LDS_W(1), s, G);
