@@ -383,10 +383,10 @@ def test_forward_shape_sweep_hits_every_kernel_route(dev, coracle):
         _check_f16(y, u, y_ref, u_ref, (T, K, N))
 
 
-@pytest.mark.parametrize("env", [{"OB_GEMM3": "2"}, {"OB_GEMM3": "0", "OB_GEMM2": "2"}])
+@pytest.mark.parametrize("env", [{"OB_GEMM3": "2"}, {"OB_GEMM3": "0", "OB_GEMM2": "2"}, {"OB_GEMM3": "2", "OB_GEMM4": "1"}])
 def test_large_tile_kernels_forced_on_ragged_shapes(dev, env):
-    """The 256 x 256 prefill kernels (LDS-DMA ob_gemm3 / register-staged ob_gemm2) are normally chosen only
-    for grids of >= 4 tiles per CU; forced here (their env switches are read once per process, hence the
+    """The 256 x 256 prefill kernels (LDS-DMA ob_gemm3 / register-staged ob_gemm2; round 6: ob_gemm4, the LDS-DMA kernel on the
+    32x32x16 MFMA, opt-in) are normally chosen only for grids of >= 4 tiles per CU; forced here (their env switches are read once per process, hence the
     child interpreter) onto small shapes with ragged last tiles in T and N, against the oracle."""
     import subprocess
     import sys
