@@ -517,6 +517,10 @@ def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, i
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     gen = sum(len(v) for v in out.values()) - 4 * 4
+    reqs = [r for r in cb.sched.finished.values() if r.max_new_tokens == new_tokens]
+    ttft = sorted(r.t_first - r.t_add for r in reqs)
+    itl = sorted((r.t_done - r.t_first) / max(len(r.out) - 1, 1) for r in reqs)
+    pct = lambda v, q: round(v[min(len(v) - 1, int(q * len(v)))] * 1e3, 2)
     stream = {"requests": requests, "prompt_tokens": "64..%d (mean %.0f)" % (prompt, sum(lens) / len(lens)), "new_tokens_each": new_tokens,
               "slots": slots, "prefill_chunk": prompt, "max_step_tokens": n_prefill * prompt + slots, "wall_s": round(dt, 3),
               "generated_tokens_per_s": round(gen / dt, 1), "all_tokens_per_s": round((gen + sum(lens)) / dt, 1),
@@ -525,6 +529,8 @@ def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, i
               "time_share_decode_steps": round(cb.time_decode / max(cb.time_mixed + cb.time_decode, 1e-9), 3),
               "ms_per_mixed_step": round(cb.time_mixed / max(cb.mixed_steps, 1) * 1e3, 2),
               "ms_per_decode_step": round(cb.time_decode / max(cb.graph_steps, 1) * 1e3, 3),
+              "time_to_first_token_ms": {"p50": pct(ttft, 0.5), "p99": pct(ttft, 0.99), "note": "all requests submitted at t = 0 (closed loop): includes the queueing for a slot"},
+              "inter_token_latency_ms": {"p50": pct(itl, 0.5), "p99": pct(itl, 0.99)},
               "engine": "onebit_mixed_step + onebit_decode_step_batched (HIP graph)" if cb._mixed is not None and cb._native is not None else "torch glue"}
     return {"step": step, "request_stream": stream, "per": "GPU", "data": "synthetic"}
 

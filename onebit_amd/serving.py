@@ -38,6 +38,9 @@ class Request:
     out: List[int] = field(default_factory=list)
     slot: Optional[int] = None
     pos: int = 0                      # tokens of this request already in its KV-cache slot
+    t_add: float = 0.0                # wall clock (time.perf_counter): submitted / first token produced / finished
+    t_first: float = 0.0
+    t_done: float = 0.0
 
     @property
     def done(self) -> bool:
@@ -90,7 +93,7 @@ class Scheduler:
             raise ValueError("request does not fit max_len")
         if self.max_step_tokens is not None and self.prefill_chunk is None and len(prompt) > self.max_step_tokens:
             raise ValueError("prompt longer than max_step_tokens")
-        r = Request(self._next, list(prompt), max_new_tokens)
+        r = Request(self._next, list(prompt), max_new_tokens, t_add=time.perf_counter())
         self._next += 1
         self.waiting.append(r)
         return r.rid
@@ -156,7 +159,10 @@ class Scheduler:
             if r.pos < len(r.prompt):
                 continue
             r.out.append(int(t))
+            if len(r.out) == 1:
+                r.t_first = time.perf_counter()
             if r.done:
+                r.t_done = time.perf_counter()
                 done.append(r)
         for r in done:
             self.running.remove(r)

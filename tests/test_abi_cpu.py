@@ -93,6 +93,59 @@ def test_argument_errors_without_gpu():
         _lib.check(1, "x")
 
 
+def test_round6_entry_points_reject_bad_arguments_without_gpu():
+    """ABI 9 (ragged rows, key-block decode attention, grouped projections, the mixed step): argument errors come back before any launch."""
+    lib = _lib.load()
+    E_ARG, E_SHAPE, E_ALIGN, E_WSPACE = -1, -2, -3, -5
+    buf = ctypes.create_string_buffer(8192)
+    a = (ctypes.addressof(buf) + 255) & ~255
+    from onebit_amd.engine import _Layer, _MixedState, _Model, _Proj, _Seg
+    # ragged rope: head_dim must be a power of two >= 16; cache rows beyond the rope tables; biases all or none; empty is fine
+    rope = lambda **kw: lib.onebit_rows_qkv_rope_ragged(a, a, a, a, a, None, kw.get("pos", a), a, a, a, kw.get("bq", None), None, None, kw.get("T", 2), 2, 2,
+                                                        kw.get("D", 64), 4, kw.get("max_len", 16), kw.get("max_pos", 16), 1e-5, None)
+    assert rope(D=48) == E_SHAPE and rope(max_len=32) == E_SHAPE and rope(bq=a) == E_ARG and rope(pos=None) == E_ARG and rope(T=0) == 0
+    # ragged attention: head_dim 64 / 128, segments inside the cache, no segments = nothing to do
+    seg = (_Seg * 2)(_Seg(0, 5, 1, 3), _Seg(5, 4, 9, 0))
+    att = lambda **kw: lib.onebit_attention_ragged(a, a, a, a, None, ctypes.cast(seg, ctypes.c_void_p), kw.get("n", 2), 4, kw.get("hkv", 4), kw.get("D", 64),
+                                                   kw.get("slots", 4), 16, None)
+    assert att(D=32) == E_SHAPE and att(hkv=3) == E_SHAPE and att(n=0) == 0
+    assert att() == E_SHAPE and b"segment 1" in lib.onebit_last_error()             # slot 9 of 4
+    # key-block decode attention: chunk a multiple of 64, scratch for more than one split
+    assert lib.onebit_attention_decode_scratch_bytes(3, 8, 1) == 0
+    assert lib.onebit_attention_decode_scratch_bytes(3, 8, 4) >= 3 * 8 * 4 * (128 + 2) * 4 + 3 * 8 * 4
+    dec = lambda **kw: lib.onebit_attention_decode_rows(a, a, a, a, None, None, a, 2, 4, 4, kw.get("D", 64), 4, 16, kw.get("chunk", 64), kw.get("ns", 1),
+                                                        None, 0, None) if True else None
+    assert dec(chunk=96) == E_SHAPE and dec(D=12) == E_SHAPE and dec(ns=3) == E_WSPACE
+    fus = lib.onebit_attention_decode_rows_fused(a, a, a, a, a, a, None, None, None, a, a, a, a, a, None, None, a, 2, 4, 4, 48, 4, 16, 16, 64, 1, 1e-5, None, 0, None)
+    assert fus == E_SHAPE                                                          # head_dim 48: the rotate_half pairing needs a power of two
+    # grouped projections: 1..3 projections, one projection beyond 64 rows goes through onebit_linear_forward
+    pr = (_Proj * 3)()
+    up = (ctypes.c_void_p * 3)(a, a, a)
+    assert lib.onebit_linear_group_prescaled(ctypes.cast(pr, ctypes.c_void_p), up, up, 0, 8, None) == E_ARG
+    assert lib.onebit_linear_group_prescaled(ctypes.cast(pr, ctypes.c_void_p), up, up, 1, 500, None) == E_SHAPE
+    assert lib.onebit_linear_group_prescaled(ctypes.cast(pr, ctypes.c_void_p), up, up, 2, 0, None) == 0
+    # the mixed step: struct size, head_dim, row accounting, workspace
+    lib.onebit_mixed_step.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_MixedState), ctypes.c_void_p]
+    lib.onebit_mixed_workspace_bytes.argtypes = [ctypes.POINTER(_Model), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    layers = (_Layer * 1)()
+    m = _Model(1, 128, 352, 2, 2, 64, 96, 32, 1e-6, 1e-5, layers, a, a, a, a, a)
+    assert lib.onebit_mixed_workspace_bytes(ctypes.byref(m), 0, 4, 0) == 0
+    nb = lib.onebit_mixed_workspace_bytes(ctypes.byref(m), 100, 4, 0)
+    assert nb > 100 * 128 * 2 * 10 and lib.onebit_mixed_workspace_bytes(ctypes.byref(m), 200, 4, 0) > nb
+    st = _MixedState()
+    assert lib.onebit_mixed_step(ctypes.byref(m), ctypes.byref(st), None) == E_ARG and b"struct_size" in lib.onebit_last_error()
+    sg = (_Seg * 1)(_Seg(1, 5, 0, 0))
+    st = _MixedState(ctypes.sizeof(_MixedState), 6, 1, 1, 1, 4, 0, 0, a, a, a, sg, a, a, None, a, a, a, 1 << 30)
+    m48 = _Model(1, 96, 352, 2, 2, 48, 96, 32, 1e-6, 1e-5, layers, a, a, a, a, a)
+    assert lib.onebit_mixed_step(ctypes.byref(m48), ctypes.byref(st), None) == E_SHAPE        # head_dim 48
+    st.n_rows = 9
+    assert lib.onebit_mixed_step(ctypes.byref(m), ctypes.byref(st), None) == E_SHAPE and b"n_rows" in lib.onebit_last_error()
+    st.n_rows, st.workspace_bytes = 6, 1024
+    assert lib.onebit_mixed_step(ctypes.byref(m), ctypes.byref(st), None) == E_WSPACE
+    st.n_rows, st.n_dec, st.n_seg = 0, 0, 0
+    assert lib.onebit_mixed_step(ctypes.byref(m), ctypes.byref(st), None) == 0                # an empty step
+
+
 def test_module_contract_matches_reference():
     m = BitLinearInf(64, 48, bias=True, dtype=torch.float16)
     assert OneBitLinear is BitLinearInf
