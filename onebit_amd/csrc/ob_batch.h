@@ -280,7 +280,9 @@ struct ObQkvRopeArgs {
     const _Float16 *b_q, *b_k, *b_v;     // [H*D], [Hkv*D], [Hkv*D]
 };
 
-template <int NV>
+// BIAS: a compile-time switch -- with the bias path as a run-time branch the bias-free kernel carried five more register arrays and ran
+// 70 % longer at 4120 rows x 5120 (82 vs 47 us: profiles/r06_mixed_step_kernels.txt, first version)
+template <int NV, bool BIAS = false>
 __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkvRopeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float red[128];
@@ -325,9 +327,9 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
         qp8[v] = __builtin_bit_cast(ob_half8, qb);
         kp8[v] = __builtin_bit_cast(ob_half8, kb);
     }
-    const bool has_b = A.b_q != nullptr;                    // (uniform)
-    ob_half8 bq8[NV], bqp8[NV], bk8[NV], bkp8[NV], bv8[NV];
-    if (has_b) {
+    constexpr bool has_b = BIAS;
+    ob_half8 bq8[BIAS ? NV : 1], bqp8[BIAS ? NV : 1], bk8[BIAS ? NV : 1], bkp8[BIAS ? NV : 1], bv8[BIAS ? NV : 1];
+    if constexpr (BIAS) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int base = (v * OB_DEC_THREADS + tid) * 8;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float x0 = ob_ln_apply((float)q8[v][i], mq, rq), x1 = ob_ln_apply((float)qp8[v][i], mq, rq);
-                if (has_b) { x0 = ob_round_h(x0 + (float)bq8[v][i]); x1 = ob_round_h(x1 + (float)bqp8[v][i]); }
+                if constexpr (BIAS) { x0 = ob_round_h(x0 + (float)bq8[v][i]); x1 = ob_round_h(x1 + (float)bqp8[v][i]); }
                 const float xr = d0 < half ? -x1 : x1;
                 o[i] = (_Float16)ob_round_h(ob_round_h(x0 * (float)c8[i]) + ob_round_h(xr * (float)s8[i]));
             }
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_qkv_rope_kernel(const ObQkv
             for (int i = 0; i < 8; ++i) {
                 float x0 = ob_ln_apply((float)k8[v][i], mk, rk), x1 = ob_ln_apply((float)kp8[v][i], mk, rk);
                 float xv = ob_ln_apply((float)v8[v][i], mv, rv);
-                if (has_b) {
+                if constexpr (BIAS) {
                     x0 = ob_round_h(x0 + (float)bk8[v][i]); x1 = ob_round_h(x1 + (float)bkp8[v][i]);
                     xv = ob_round_h(xv + (float)bv8[v][i]);
                 }

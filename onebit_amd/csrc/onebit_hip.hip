@@ -35,11 +35,13 @@
                           hipLaunchKernelGGL((ob_b_swiglu_kernel<2>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
                           hipLaunchKernelGGL((ob_b_swiglu_kernel<3>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
                           hipLaunchKernelGGL((ob_b_swiglu_kernel<4>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
+#define OB_LAUNCH_QKVROPE_B(BIAS_, WIDTH, GRID, STREAM, ARGS) \
+    OB_NV_DISPATCH(WIDTH, hipLaunchKernelGGL((ob_qkv_rope_kernel<1, BIAS_>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<2, BIAS_>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<3, BIAS_>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
+                          hipLaunchKernelGGL((ob_qkv_rope_kernel<4, BIAS_>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
 #define OB_LAUNCH_QKVROPE(WIDTH, GRID, STREAM, ARGS) \
-    OB_NV_DISPATCH(WIDTH, hipLaunchKernelGGL((ob_qkv_rope_kernel<1>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
-                          hipLaunchKernelGGL((ob_qkv_rope_kernel<2>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
-                          hipLaunchKernelGGL((ob_qkv_rope_kernel<3>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS), \
-                          hipLaunchKernelGGL((ob_qkv_rope_kernel<4>), GRID, dim3(OB_DEC_THREADS), 0, STREAM, ARGS))
+    do { if ((ARGS).b_q) OB_LAUNCH_QKVROPE_B(true, WIDTH, GRID, STREAM, ARGS); else OB_LAUNCH_QKVROPE_B(false, WIDTH, GRID, STREAM, ARGS); } while (0)
 
 static thread_local char g_err[256] = "";
 
