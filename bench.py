@@ -497,7 +497,7 @@ def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, i
     step = {"decode_rows": n_dec, "decode_context": ctx, "prefill_segments": n_prefill, "prefill_tokens_each": prompt, "rows": rows,
             "ms": round(med, 3), "ms_min": round(ts[0], 3), "iterations": iters, "tokens_per_s": round(rows / med * 1e3, 1),
             "onebit_layer_TFLOPs_equivalent": round(2.0 * rows * w1 / med / 1e9, 1),
-            "launches_per_layer": "norm, q, k, v, rope, flash (prompt chunks), split-KV (decode rows), o, norm, gate, up, swiglu, down = 13",
+            "launches_per_layer": "norm, q|k|v (one grouped GEMM), rope / append, flash (prompt chunks), key-block (decode rows), o, norm, gate|up (grouped), swiglu, down = 10",
             "engine": "onebit_mixed_step"}
     del ms, caches
     torch.cuda.empty_cache()
