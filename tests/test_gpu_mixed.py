@@ -399,3 +399,57 @@ def test_fused_decode_rows_equals_rope_launch_plus_attention(H, Hkv, D, chunk, b
     assert float((k0 != k1).float().mean()) < 0.01
     changed = (k1 != base_k).any(-1).sum().item()                                   # exactly one row per (live request, kv head) was appended
     assert changed == (rows - 1) * Hkv
+
+
+def test_mixed_step_full_size_properties():
+    """BASELINE config 5's step at its real width and row count (LLaMA2-13B widths, 2 layers; 8 x 512 prompt tokens + 24 decode rows = 4120
+    rows) through size-independent properties: (1) the step is deterministic and idempotent (the same items twice: bit-identical logits --
+    fixed-order combines, tickets back at zero, the same cache rows rewritten); (2) the ORDER of the items does not matter: every item's
+    logits are bit-identical under a permutation (a row's sums never mix with other rows': the GEMM's token columns, the row kernels, the
+    ragged attention's segments are independent); (3) a prompt entering as one 512-token chunk or as 256 + 256 gives the same greedy token
+    and logits within fp16 tolerance (the attention's key blocks split differently)."""
+    from onebit_amd.engine import MixedStep
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device(DEV)
+    cfg = OneBitLlamaConfig(vocab_size=1024, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2, num_attention_heads=40,
+                            max_position_embeddings=1024)
+    model = build_synthetic_model(cfg, seed=5, device=dev)
+    slots, max_len = 32, 700
+    g = torch.Generator().manual_seed(2)
+    rnd = lambda n: torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist()
+
+    def fresh():
+        shape = (slots, cfg.num_key_value_heads, max_len, cfg.head_dim)
+        caches = [(torch.zeros(shape, dtype=torch.float16, device=dev), torch.zeros(shape, dtype=torch.float16, device=dev)) for _ in range(cfg.num_hidden_layers)]
+        return MixedStep(model, caches, slots, max_len, max_rows=4200, keep_logits=True)
+    hist = [(s, 0, rnd(100 + 3 * s)) for s in range(24)]
+    items = [(s, 100 + 3 * s, rnd(1)) for s in range(24)] + [(24 + i, 0, rnd(512)) for i in range(8)]
+    ms = fresh()
+    ms.launch(hist)
+    n1 = ms.launch(items).clone()
+    l1 = ms.logits[:len(items)].clone()
+    n2 = ms.launch(items).clone()
+    l2 = ms.logits[:len(items)].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(n1, n2)                                  # (1)
+    assert torch.isfinite(l1.float()).all() and len(set(n1.tolist())) > 4
+    perm = torch.randperm(len(items), generator=g).tolist()
+    ms2 = fresh()
+    ms2.launch(hist)
+    n3 = ms2.launch([items[j] for j in perm]).clone()
+    l3 = ms2.logits[:len(items)].clone()
+    torch.cuda.synchronize()
+    for pos_, j in enumerate(perm):                                                     # (2)
+        assert torch.equal(l3[pos_], l1[j]) and int(n3[pos_]) == int(n1[j]), (pos_, j)
+    ms3 = fresh()
+    ms3.launch(hist)
+    toks = items[24][2]
+    ms3.launch([(24, 0, toks[:256])])
+    n4 = ms3.launch([(24, 256, toks[256:])]).clone()
+    l4 = ms3.logits[0].float().clone()
+    torch.cuda.synchronize()
+    ref = l1[24].float()
+    assert float((l4 - ref).abs().max()) < 1e-2 * float(ref.abs().max())               # (3)
+    srt = ref.sort().values
+    if float(srt[-1] - srt[-2]) > 2e-2 * float(ref.abs().max()):
+        assert int(n4[0]) == int(n1[24])
