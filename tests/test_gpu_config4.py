@@ -9,6 +9,8 @@ finishes the rows.  Here the n ranks' calls run one after the other on cuda:0 on
 bytes at 13B) and the partials are added in rank order -- the arithmetic of the N-rank job without the wire.
 Checked against the oracle's complete layer: u within 2 fp16 ulps, y rel-L2 <= 1e-3.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -234,3 +236,23 @@ def test_fused_k_sharded_decoder_gqa_and_bias_vs_engine(name, cfgkw, world):
         for d in decs[1:]:
             assert torch.equal(d.buf["logits"], decs[0].buf["logits"])
         tok = int(ref.argmax())
+
+
+@pytest.mark.parametrize("world", [2])
+def test_fused_k_sharded_decoder_two_ranks_rccl(world):
+    """The multi-rank path for real (advisor, round 5): `world` processes, one GPU each, torch.distributed all_reduce = RCCL over xGMI --
+    eager and captured with the segment kernels in one HIP graph -- against the one-device lockstep emulation the other tests use.
+    Needs `world` GPUs: skipped on the 1-GPU test boxes; the driver's 8-GPU scaling run is where it applies."""
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kshard_rccl_child.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), child]
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "kshard-rccl ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
