@@ -569,8 +569,10 @@ struct ObG3Group {
     int N[3], nbn[3], tile_end[3];
     long long ldw_words, lda;
     int T, K;
+    float *zp[3];                 // PARTIAL instances: fp32 sums [T, N] per problem (K-slices of ONE projection: W / a advanced to the slice)
+    int Ks[3];                    //   and each slice's own length (multiples of 256)
 };
-template <int WT>
+template <int WT, bool PARTIAL = false>
 __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3g_f16_kernel(const ObG3Group G)
 {
     const int bid = ob_g3_bid();
@@ -580,9 +582,11 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3g_f16_kernel(const ObG3Gr
     const _Float16 *a = p == 0 ? G.a[0] : (p == 1 ? G.a[1] : G.a[2]);
     const _Float16 *g = p == 0 ? G.g[0] : (p == 1 ? G.g[1] : G.g[2]);
     _Float16 *u = p == 0 ? G.u[0] : (p == 1 ? G.u[1] : G.u[2]);
+    float *zp = PARTIAL ? (p == 0 ? G.zp[0] : (p == 1 ? G.zp[1] : G.zp[2])) : nullptr;
     const int N = p == 0 ? G.N[0] : (p == 1 ? G.N[1] : G.N[2]);
     const int nbn = p == 0 ? G.nbn[0] : (p == 1 ? G.nbn[1] : G.nbn[2]);
-    ob_gemm3_body<false, WT>(W, G.ldw_words, a, G.lda, g, u, nullptr, G.T, G.K, N, nbn, bid - b0);
+    const int K = PARTIAL ? (p == 0 ? G.Ks[0] : (p == 1 ? G.Ks[1] : G.Ks[2])) : G.K;
+    ob_gemm3_body<PARTIAL, WT>(W, G.ldw_words, a, G.lda, g, u, zp, G.T, K, N, nbn, bid - b0);
 }
 #undef RN
 #undef RT

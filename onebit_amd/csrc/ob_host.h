@@ -46,6 +46,9 @@ struct ObRowsNormCall {
     const void *h_next[3]; void *x_scaled[3]; int n_scaled;
     const int32_t *rows;
     int64_t T; int H; float rms_eps, ln_eps;
+    // instead of u_prev: the previous projection as two K-slices' fp32 sums (ob_gemm3_ksplit2) + its weight_scale:
+    // u = fp16(fp16(z0 + z1) * g_prev) (bitnet.py:115-116) is formed by the row kernel
+    const float *z0, *z1; const void *g_prev;
 };
 OB_HIDDEN int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s);
 // fp16 lm_head for B <= 64 rows + greedy token per row (ob_b_lmhead_kernel + ob_b_argmax_kernel)
@@ -59,3 +62,11 @@ OB_HIDDEN int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, cons
 // their pre-scaled rows a[i] [T, K]: u[i] = fp16(fp16(W_i . a_i) * g_i).  ONEBIT_E_SHAPE when the group is not eligible (the caller
 // falls back to onebit_linear_forward per projection).
 OB_HIDDEN int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s);
+// the eligibility test of ob_gemm3_grouped alone (shapes, pitches, the weights' alignment, the GROUP's tile count against the CU count;
+// rows / outputs assumed 16-byte aligned): a caller that is about to choose between pre-scaled rows for the group and plain rows asks first
+OB_HIDDEN bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T);
+// ONE projection on its pre-scaled rows a [T, K] as TWO K-slices in one launch of the LDS-DMA GEMM (fp32 sums z0, z1 [T, N], added and
+// scaled by the consuming row kernel): a hidden-width projection at a few hundred rows has too few 256 x 128 tiles for the chip (13B, 543 rows:
+// 100), its two halves have twice as many.  ob_gemm3_ksplit2_ok: the projection alone is NOT eligible for the LDS-DMA GEMM, its halves are.
+OB_HIDDEN bool ob_gemm3_ksplit2_ok(const onebit_proj_t &p, int64_t T);
+OB_HIDDEN int ob_gemm3_ksplit2(const onebit_proj_t &p, const void *a, float *z0, float *z1, int64_t T, hipStream_t s);

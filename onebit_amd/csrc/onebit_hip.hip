@@ -1543,12 +1543,13 @@ int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s)
     if (c.T <= 0) return 0;
     if (c.H <= 0 || c.H % 8 != 0 || c.H > OB_DEC_MAXV * OB_DEC_THREADS * 8 || c.n_scaled < 0 || c.n_scaled > 3 || c.T > 0x7fffffffLL)
         return ob_fail(ONEBIT_E_SHAPE, "rows_norm: bad shape");
-    if (!c.rms_w || !c.hres_out || (!c.x && c.n_scaled == 0) || (c.embed ? !c.tokens : (!c.hres_in || !c.u_prev)))
+    if (!c.rms_w || !c.hres_out || (!c.x && c.n_scaled == 0) || (c.embed ? !c.tokens : (!c.hres_in || (!c.u_prev && !(c.z0 && c.g_prev)))))
         return ob_fail(ONEBIT_E_ARG, "rows_norm: null pointer");
     ObBNormArgs a = {};
     a.embed = (const _Float16 *)c.embed; a.tokens = c.tokens; a.hres_in = (const _Float16 *)c.hres_in; a.u_prev = (const _Float16 *)c.u_prev;
     a.bias_prev = (const _Float16 *)c.bias_prev; a.rms_w = (const _Float16 *)c.rms_w; a.hres_out = (_Float16 *)c.hres_out; a.x = (_Float16 *)c.x;
     a.H = c.H; a.rms_eps = c.rms_eps; a.ln_eps = c.ln_eps; a.n_scaled = c.n_scaled; a.rows = c.rows;
+    if (!c.embed && !c.u_prev) { a.z0 = c.z0; a.z1 = c.z1; a.g_prev = (const _Float16 *)c.g_prev; }
     for (int i = 0; i < c.n_scaled; ++i) {
         if (!c.h_next[i] || !c.x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_norm: null scaled output %d", i);
         a.h_next[i] = (const _Float16 *)c.h_next[i]; a.x_scaled[i] = (_Float16 *)c.x_scaled[i];
@@ -1556,6 +1557,24 @@ int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s)
     if (c.embed) OB_LAUNCH_NORM(true, c.H, dim3((unsigned)c.T), s, a);
     else OB_LAUNCH_NORM(false, c.H, dim3((unsigned)c.T), s, a);
     return ob_launch_status("rows_norm");
+}
+
+bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T)
+{
+    static const int env = getenv("OB_GEMM3_GROUPED") ? atoi(getenv("OB_GEMM3_GROUPED")) : 1;
+    static const int env3 = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
+    if (!env || !env3 || np < 2 || np > 3) return false;
+    const int64_t K = ps[0]->K, ldw = ps[0]->ldw_bytes;
+    if (T < 192 || K % (4 * OB_G2_K) != 0 || T * K * 2 >= ((int64_t)1 << 32) || ldw % 16 != 0) return false;
+    int64_t tiles = 0;
+    for (int i = 0; i < np; ++i) {
+        const onebit_proj_t &p = *ps[i];
+        if (!p.weight || !p.weight_scale || p.K != K || p.ldw_bytes != ldw || p.N % 4 != 0 || p.N * (K / 8) >= ((int64_t)1 << 32) ||
+            p.N * ldw >= ((int64_t)1 << 32) || !ob_aligned(p.weight, 16) || !ob_aligned(p.weight_scale, 8))
+            return false;
+        tiles += ((p.N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
+    }
+    return 3 * tiles >= 2 * (int64_t)ob_cu_count() && tiles <= 0x3fffffff;
 }
 
 int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
@@ -1594,6 +1613,37 @@ int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void
     ob_set_max_lds_once(ob_gemm3g_f16_kernel<1>, attr_set, OB_G3_LDS_W(1));
     hipLaunchKernelGGL((ob_gemm3g_f16_kernel<1>), dim3((unsigned)tiles), dim3(256), OB_G3_LDS_W(1), s, G);
     return ob_launch_status("gemm3_grouped");
+}
+
+bool ob_gemm3_ksplit2_ok(const onebit_proj_t &p, int64_t T)
+{
+    static const int env = getenv("OB_GEMM3_KSPLIT") ? atoi(getenv("OB_GEMM3_KSPLIT")) : 1;         // A/B: 0 = the 128 x 128 kernel on plain rows
+    static const int env3 = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
+    if (!env || !env3 || T < 192 || p.K % (4 * OB_G2_K) != 0 || p.K < 8 * OB_G2_K || p.N % 4 != 0 || T * p.K * 2 >= ((int64_t)1 << 32) || p.ldw_bytes % 16 != 0 ||
+        p.N * p.ldw_bytes >= ((int64_t)1 << 32) || !p.weight || !p.weight_scale || !ob_aligned(p.weight, 16) || !ob_aligned(p.weight_scale, 16))
+        return false;
+    const int64_t tiles = ((p.N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
+    const int64_t cus = ob_cu_count();
+    return 3 * tiles < 2 * cus && 3 * 2 * tiles >= 2 * cus;          // not eligible alone, eligible as two slices
+}
+
+int ob_gemm3_ksplit2(const onebit_proj_t &p, const void *a, float *z0, float *z1, int64_t T, hipStream_t s)
+{
+    if (!ob_gemm3_ksplit2_ok(p, T) || !a || !z0 || !z1 || !ob_aligned(a, 16) || !ob_aligned(z0, 16) || !ob_aligned(z1, 16))
+        return ob_fail(ONEBIT_E_SHAPE, "gemm3_ksplit2: not eligible");
+    const int64_t Kh = (p.K / (4 * OB_G2_K) + 1) / 2 * (4 * OB_G2_K);          // slices of whole 256-element quads: 7B down_proj 11008 = 5632 + 5376
+    ObG3Group G = {};
+    const int nbn = (int)((p.N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + 127) / 128);
+    for (int i = 0; i < 3; ++i) {
+        const int j = i < 2 ? i : 1;
+        G.W[i] = (const uint32_t *)p.weight + j * (Kh / 32); G.a[i] = (const _Float16 *)a + j * Kh; G.g[i] = nullptr; G.u[i] = nullptr;
+        G.zp[i] = j == 0 ? z0 : z1; G.Ks[i] = (int)(j == 0 ? Kh : p.K - Kh); G.N[i] = (int)p.N; G.nbn[i] = nbn; G.tile_end[i] = nbn * nbt * (j + 1);
+    }
+    G.ldw_words = p.ldw_bytes / 4; G.lda = p.K; G.T = (int)T; G.K = (int)Kh;
+    static bool attr_set[OB_MAX_DEVICES] = {};
+    ob_set_max_lds_once(ob_gemm3g_f16_kernel<1, true>, attr_set, OB_G3_LDS_W(1));
+    hipLaunchKernelGGL((ob_gemm3g_f16_kernel<1, true>), dim3((unsigned)(2 * nbn * nbt)), dim3(256), OB_G3_LDS_W(1), s, G);
+    return ob_launch_status("gemm3_ksplit2");
 }
 
 int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)

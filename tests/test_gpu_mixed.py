@@ -265,6 +265,37 @@ def test_mixed_step_at_13b_widths_chunked_prompts_next_to_decoding_slots():
         assert out[rid] == ref or _near_tie(model, p, ref, out[rid], dev), rid
 
 
+@pytest.mark.parametrize("hidden,inter,heads,rows", [(5120, 13824, 40, 543), (5120, 13824, 40, 700), (4096, 11008, 32, 700)])
+def test_mixed_step_mid_size_routes(hidden, inter, heads, rows):
+    """A few hundred rows at 13B / 7B widths (7B down_proj: K = 11008 splits into 5632 + 5376): q|k|v and gate|up take pre-scaled rows because the GROUP fills the chip (ob_gemm3_group_ok),
+    o_proj / down_proj run as two K-slices whose fp32 sums the next row kernel adds (ob_gemm3_ksplit2).  Logits of the prompt's last row
+    and of the decode rows against the module path."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.engine import MixedStep
+    dev = torch.device(DEV)
+    cfg = OneBitLlamaConfig(vocab_size=512, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=2,
+                            num_attention_heads=heads, max_position_embeddings=1024)
+    model = build_synthetic_model(cfg, seed=29, device=dev)
+    slots, max_len, n_dec = 4, 800, 3
+    shape = (slots, cfg.num_key_value_heads, max_len, cfg.head_dim)
+    caches = [(torch.zeros(shape, dtype=torch.float16, device=dev), torch.zeros(shape, dtype=torch.float16, device=dev)) for _ in range(cfg.num_hidden_layers)]
+    ms = MixedStep(model, caches, slots, max_len, max_rows=1024, keep_logits=True)
+    g = torch.Generator().manual_seed(rows)
+    seqs = {s: torch.randint(0, 512, (n,), generator=g).tolist() for s, n in [(0, 20), (1, 7), (2, 33), (3, rows - n_dec)]}
+    ms.launch([(s, 0, seqs[s][:-1]) for s in range(n_dec)])
+    torch.cuda.synchronize()
+    items = [(s, len(seqs[s]) - 1, seqs[s][-1:]) for s in range(n_dec)] + [(3, 0, seqs[3])]
+    assert sum(len(t) for _, _, t in items) == rows
+    nxt = ms.launch(items).clone()
+    torch.cuda.synchronize()
+    lg = ms.logits[:len(items)].float()
+    for i, (slot, start, toks) in enumerate(items):
+        ref = model(torch.tensor([seqs[slot]], device=dev))[0, -1].float()
+        scale = float(ref.abs().max())
+        assert float((lg[i] - ref).abs().max()) < 1e-2 * scale, (i, slot)
+        assert int(nxt[i]) == int(lg[i].argmax())
+
+
 @pytest.mark.parametrize("chunk,ctxs", [(64, [1, 5, 63, 64, 65, 130, 200]), (128, [7, 128, 129, 255, 256, 300, 2])])
 def test_batched_step_keyblock_attention_matches_the_one_workgroup_form(chunk, ctxs):
     """onebit_decode_step_batched with attn_splits (LayerNorm + RoPE + append launch, then (head, slot, split) workgroups) against
