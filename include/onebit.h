@@ -397,6 +397,14 @@ typedef struct onebit_kshard_state {
     int32_t *part_idx;          /* int32 [1024]                                                                       */
     float *tile_stats;          /* fp32 [onebit_decode_stats_floats(model)]                                           */
     int32_t k0_hidden, k0_attn, k0_inter;   /* slice origin for in_features = hidden / n_heads*D / intermediate       */
+    /* (appended in ABI 9) attn_chunk > 0: the attention of ONEBIT_KSEG_ATTN_O takes the key-block form of the other engines
+     * (onebit_attention_decode_rows_fused: attn_splits workgroups per head, each over attn_chunk cached tokens, attn_chunk % 64 == 0,
+     * attn_splits * attn_chunk >= max_len) after one launch that rounds and scales the reduced q | k | v sums into u_q / u_k / u_v
+     * with their LayerNorm partials -- for contexts where one workgroup per head streaming the whole cache is the step's longest
+     * launch, and for max_len beyond the one-workgroup kernel's 64 KB of LDS.  head_dim a power of two >= 16.
+     * attn_scratch: onebit_attention_decode_scratch_bytes(1, n_heads, attn_splits) bytes, zeroed once by the caller.          */
+    int32_t attn_chunk, attn_splits;
+    void *attn_scratch;
 } onebit_kshard_state_t;
 int onebit_decode_step_ksharded(const onebit_model_t *model, const onebit_kshard_state_t *state, int32_t layer,
                                 int32_t segment, void *stream);

@@ -1928,6 +1928,10 @@ extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit
     const int H = m->hidden, I = m->intermediate, D = m->head_dim, NQ = m->n_heads * D, NK = m->n_kv_heads * D;
     if (st->k0_hidden < 0 || st->k0_attn < 0 || st->k0_inter < 0 || st->k0_hidden % 128 || st->k0_attn % 128 || st->k0_inter % 128)
         return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: slice origins must be multiples of 128");
+    if (st->attn_chunk != 0 && (st->attn_chunk < 0 || st->attn_chunk % 64 != 0 || st->attn_splits < 1 || st->attn_splits > 64 ||
+                                (int64_t)st->attn_splits * st->attn_chunk < m->max_len || (st->attn_splits > 1 && !st->attn_scratch) ||
+                                (D & (D - 1)) != 0 || D < 16))
+        return ob_fail(ONEBIT_E_ARG, "decode_step_ksharded: attn_chunk %d needs a multiple of 64, 1..64 attn_splits covering max_len, attn_scratch and a power-of-two head_dim", st->attn_chunk);
     _Float16 *hA = (_Float16 *)st->hres0, *hB = (_Float16 *)st->hres1;
     ObStatsLayout sl = ob_stats_layout(m);
     float *ts = st->tile_stats;
@@ -2008,11 +2012,28 @@ extern "C" int onebit_decode_step_ksharded(const onebit_model_t *m, const onebit
         at.z_q = st->z_qkv; at.z_k = st->z_qkv + NQ; at.z_v = st->z_qkv + NQ + NK;
         at.g_q = (const _Float16 *)L.q.weight_scale; at.g_k = (const _Float16 *)L.k.weight_scale; at.g_v = (const _Float16 *)L.v.weight_scale;
         at.b_q = (const _Float16 *)L.q_bias; at.b_k = (const _Float16 *)L.k_bias; at.b_v = (const _Float16 *)L.v_bias;
-        const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
-        if (attn_lds > 64 * 1024) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: max_len %d too large for the attention kernel", m->max_len);
-        if (qkv_bias) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, true, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
-        else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, false, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
-        if ((rc = ob_launch_status("decode_step_ksharded(attn)"))) return rc;
+        if (st->attn_chunk > 0) {
+            // key-block form: u = fp16(fp16(z) * g) of the three reduced sums + their LayerNorm partials in one row launch, then the
+            // attention launch of the other engines' long-context route (split over the cached tokens, q / k / v formed inside)
+            ObBZgArgs za = {};
+            za.s[0] = {st->z_qkv, (const _Float16 *)L.q.weight_scale, (_Float16 *)st->u_q, ts_q, NQ, 0};
+            za.s[1] = {st->z_qkv + NQ, (const _Float16 *)L.k.weight_scale, (_Float16 *)st->u_k, ts_k, NK, 0};
+            za.s[2] = {st->z_qkv + NQ + NK, (const _Float16 *)L.v.weight_scale, (_Float16 *)st->u_v, ts_v, NK, 0};
+            if ((rc = launch_zg(za, 3))) return rc;
+            const size_t sbytes = onebit_attention_decode_scratch_bytes(1, m->n_heads, st->attn_splits);
+            if ((rc = onebit_attention_decode_rows_fused(st->u_q, st->u_k, st->u_v, ts_q, ts_k, ts_v, L.q_bias, L.k_bias, L.v_bias, m->rope_cos,
+                                                         m->rope_sin, L.k_cache, L.v_cache, st->attn_out, nullptr, nullptr, st->pos, 1, m->n_heads,
+                                                         m->n_kv_heads, D, 1, m->max_len, m->max_len, st->attn_chunk, st->attn_splits, m->ln_eps,
+                                                         st->attn_scratch, sbytes, s)))
+                return rc;
+        } else {
+            const size_t attn_lds = 512 + 3 * 128 * 2 + (size_t)OB_ATTN_WAVES * 128 * 4 + (size_t)4 * m->max_len;
+            if (attn_lds > 64 * 1024)
+                return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: max_len %d too large for the one-workgroup attention kernel (set attn_chunk)", m->max_len);
+            if (qkv_bias) hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, true, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
+            else hipLaunchKernelGGL((ob_dec_attn_kernel<false, 512, true, false, true>), dim3(m->n_heads), dim3(512), attn_lds, s, at, ObPfPlan{});
+            if ((rc = ob_launch_status("decode_step_ksharded(attn)"))) return rc;
+        }
         a.nproj = 1; a.K = (int)L.o.K;
         if (st->k0_attn + L.o.K > NQ) return ob_fail(ONEBIT_E_SHAPE, "decode_step_ksharded: o_proj slice of layer %d leaves the input vector", l);
         if ((rc = ob_kshard_proj(a.p[0], L.o, st->z_o, H, NQ, "o_proj"))) return rc;

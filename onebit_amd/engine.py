@@ -63,13 +63,14 @@ class _BatchState(ctypes.Structure):
                 ("attn_splits", _i32), ("attn_chunk", _i32), ("q_rows", _vp), ("attn_scratch", _vp)]      # ABI 9: key-block attention
 
 
-class _KState(ctypes.Structure):      # onebit_kshard_state_t (ABI 8)
+class _KState(ctypes.Structure):      # onebit_kshard_state_t (ABI 8; the attention fields: ABI 9)
     _fields_ = [("struct_size", ctypes.c_uint64), ("token", _vp), ("pos", _vp), ("out_tokens", _vp), ("max_out", _i32),
                 ("hres0", _vp), ("hres1", _vp), ("x", _vp), ("u_q", _vp), ("u_k", _vp), ("u_v", _vp), ("attn_out", _vp),
                 ("u_gate", _vp), ("u_up", _vp), ("act", _vp), ("u_down", _vp),
                 ("z_qkv", _vp), ("z_o", _vp), ("z_gu", _vp), ("z_down", _vp),
                 ("logits", _vp), ("part_val", _vp), ("part_idx", _vp), ("tile_stats", _vp),
-                ("k0_hidden", _i32), ("k0_attn", _i32), ("k0_inter", _i32)]
+                ("k0_hidden", _i32), ("k0_attn", _i32), ("k0_inter", _i32),
+                ("attn_chunk", _i32), ("attn_splits", _i32), ("attn_scratch", _vp)]
 
 
 KSEG_QKV, KSEG_ATTN_O, KSEG_GATE_UP, KSEG_DOWN, KSEG_HEAD = 0, 1, 2, 3, 4

@@ -518,7 +518,18 @@ class _HipSegments:
                               p(dec.z_qkv), p(dec.z_o), p(dec.z_gu), p(dec.z_down),
                               p(b["logits"]), p(b["part_val"]), p(b["part_idx"]), p(self._tile_stats),
                               dec.kr(dec.cfg.hidden_size)[0], dec.kr(dec.cfg.num_attention_heads * dec.cfg.head_dim)[0],
-                              dec.kr(dec.cfg.intermediate_size)[0])
+                              dec.kr(dec.cfg.intermediate_size)[0], 0, 0, None)
+        if dec.attn_chunk:
+            # key-block attention: ONE graph serves every context, so the split count covers max_len (splits past a step's
+            # context leave at once)
+            splits = -(-dec.max_len // dec.attn_chunk)
+            if splits > 64:
+                raise ValueError(f"attn_chunk {dec.attn_chunk} gives {splits} > 64 attention splits at max_len {dec.max_len}")
+            self.lib.onebit_attention_decode_scratch_bytes.restype = ctypes.c_size_t
+            nb = int(self.lib.onebit_attention_decode_scratch_bytes(1, dec.cfg.num_attention_heads, splits))
+            self._attn_scratch = torch.zeros(max(nb, 16), dtype=torch.uint8, device=dec.dev)
+            self._state.attn_chunk, self._state.attn_splits = dec.attn_chunk, splits
+            self._state.attn_scratch = self._attn_scratch.data_ptr()
         self.lib.onebit_decode_step_ksharded.restype = ctypes.c_int
         self.lib.onebit_decode_step_ksharded.argtypes = [ctypes.POINTER(_Model), ctypes.POINTER(_KState), ctypes.c_int32, ctypes.c_int32,
                                                          ctypes.c_void_p]
@@ -537,12 +548,18 @@ class FusedKShardedDecoder:
     column window of every packed matrix (1/world of the weight bytes per token).  ``group``: the process group of the K
     shards (default: the world group when ``world`` > 1).  ``reduce_fn(t)``: replaces the all-reduce (tests drive several
     ranks in one process).  ``backend(dec)``: an object with ``segment(layer, seg)`` (default: the C ABI).  ``granule``:
-    slice boundaries in columns (the C ABI needs 128; CPU stand-ins of the segments may use 32 on toy widths)."""
+    slice boundaries in columns (the C ABI needs 128; CPU stand-ins of the segments may use 32 on toy widths).
+    ``attn_chunk``: cached tokens per attention workgroup of the key-block form (``onebit_kshard_state_t.attn_chunk``); None = that
+    form with 256 (512, ... : at most 64 workgroups per head) tokens per workgroup when ``max_len`` > ``long_context_from``, else the
+    one-workgroup-per-head launch (one launch fewer per layer; its LDS holds a score per cached token); 0 = always the latter.
+    13B shapes, N = 1 (tools/kshard_ctx_probe.py): 2.03 ms / token either way at 16 cached tokens, 2.07 vs 2.11 at 128,
+    2.85 vs 2.21 at 512, 5.05 vs 2.41 at 2000."""
 
     SEGMENTS = (0, 1, 2, 3)          # ONEBIT_KSEG_QKV, _ATTN_O, _GATE_UP, _DOWN; 4 = _HEAD once per token
 
     def __init__(self, model: torch.nn.Module, rank: int, world: int, max_len: int, group=None, use_graph: bool = True,
-                 reduce_fn: Optional[Callable] = None, backend: Optional[Callable] = None, granule: int = 128):
+                 reduce_fn: Optional[Callable] = None, backend: Optional[Callable] = None, granule: int = 128,
+                 attn_chunk: Optional[int] = None, long_context_from: int = 256):
         from .llama import KVCache
         cfg = model.config
         p = model.lm_head.weight
@@ -559,6 +576,15 @@ class FusedKShardedDecoder:
             raise ValueError("max_len exceeds max_position_embeddings")
         H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
         NQ, NK = cfg.num_attention_heads * D, cfg.num_key_value_heads * D
+        if attn_chunk is None:
+            attn_chunk = 0
+            if self.max_len > long_context_from and D >= 16 and D & (D - 1) == 0:
+                attn_chunk = 256
+                while -(-self.max_len // attn_chunk) > 64:
+                    attn_chunk *= 2
+        if attn_chunk < 0 or attn_chunk % 64:
+            raise ValueError("attn_chunk must be a non-negative multiple of 64")
+        self.attn_chunk = int(attn_chunk)
         if backend is None and granule % 128:
             raise ValueError("the HIP segments need slice boundaries on multiples of 128 columns (16-byte weight loads)")
         for K in (H, NQ, I):

@@ -238,6 +238,69 @@ def test_fused_k_sharded_decoder_gqa_and_bias_vs_engine(name, cfgkw, world):
         tok = int(ref.argmax())
 
 
+@pytest.mark.parametrize("name,cfgkw,world,chunk", [
+    ("mha", dict(vocab_size=512, hidden_size=1024, intermediate_size=2816, num_hidden_layers=2, num_attention_heads=8,
+                 max_position_embeddings=512), 1, 64),
+    ("gqa", dict(vocab_size=640, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=8,
+                 num_key_value_heads=2, max_position_embeddings=512), 2, 128),
+    ("bias", dict(vocab_size=512, hidden_size=512, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=4,
+                  max_position_embeddings=512, attention_bias=True), 2, 64),
+])
+def test_fused_k_sharded_decoder_keyblock_attention(name, cfgkw, world, chunk):
+    """onebit_kshard_state_t.attn_chunk (round 6): the attention segment as [scale + LayerNorm partials of the reduced q | k | v sums]
+    + the key-block attention launch, against the SAME decoder on the one-workgroup-per-head launch, teacher-forced across the
+    split boundaries (contexts chunk - 2 .. chunk + 3 and 2 chunk - 1 .. 2 chunk + 2) -- logits within fp16 noise of two softmax
+    summation orders, appended keys / values equal to 2^-9 -- and free-running under ONE graph against the single-GPU engine."""
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    from onebit_amd.sharded import FusedKShardedDecoder, lockstep_step
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(**cfgkw)
+    model = build_synthetic_model(cfg, seed=37, device=dev)
+    max_len = 3 * chunk + 8
+    mk = lambda ac: [FusedKShardedDecoder(model, r, world, max_len=max_len, use_graph=False, reduce_fn=lambda t: None, attn_chunk=ac)
+                     for r in range(world)]
+    kb, one = mk(chunk), mk(0)
+    assert kb[0].backend._state.attn_chunk == chunk and kb[0].backend._state.attn_splits == -(-max_len // chunk)
+    assert one[0].backend._state.attn_chunk == 0
+    assert FusedKShardedDecoder(model, 0, 1, max_len=max_len, use_graph=False, long_context_from=1024).attn_chunk == 0
+    assert FusedKShardedDecoder(model, 0, 1, max_len=max_len, use_graph=False, long_context_from=64).attn_chunk == 256
+    g = torch.Generator().manual_seed(9)
+    for S in (chunk - 2, 2 * chunk - 1):
+        ids = torch.randint(0, cfg.vocab_size, (1, S), generator=g).to(dev)
+        for d in kb + one:
+            d.prime(ids)
+        tok = one[0].first_token
+        for i in range(5):
+            for d in kb + one:
+                d.set_state(tok, S + i)
+            lockstep_step(kb); lockstep_step(one)
+            torch.cuda.synchronize()
+            got, ref = kb[0].logits().cpu().numpy(), one[0].logits().cpu().numpy()
+            scale = float(np.abs(ref).max())
+            assert np.abs(got - ref).max() <= 4e-3 * scale, (name, S, i, float(np.abs(got - ref).max()), scale)
+            srt = np.sort(ref)
+            if srt[-1] - srt[-2] > 1e-2 * scale:
+                assert int(got.argmax()) == int(ref.argmax())
+            for (ka, va), (kb_, vb) in zip(kb[0].cache.layers, one[0].cache.layers):
+                assert float((ka[0, :, :S + i + 1].float() - kb_[0, :, :S + i + 1].float()).abs().max()) <= 2.0 ** -9 * 8
+                assert float((va[0, :, :S + i + 1].float() - vb[0, :, :S + i + 1].float()).abs().max()) <= 2.0 ** -9 * 8
+            for d in kb[1:]:
+                assert torch.equal(d.buf["logits"], kb[0].buf["logits"])
+            tok = int(ref.argmax())
+    if world == 1:          # one graph for every context, free-running across a split boundary
+        ids = torch.randint(0, cfg.vocab_size, (1, chunk - 4), generator=g).to(dev)
+        eng = DecodeEngine(model, max_len=max_len)
+        ref = eng.generate(ids, 12)[0, ids.shape[1]:].tolist()
+        dec = FusedKShardedDecoder(model, 0, 1, max_len=max_len, attn_chunk=chunk)
+        got = dec.generate(ids, 12)
+        assert dec.graph is not None
+        if got != ref:
+            j = next(i for i in range(len(ref)) if got[i] != ref[i])
+            lg = model(torch.tensor([ids[0].tolist() + ref[:j]], device=dev))[0, -1]
+            assert abs(float(lg[got[j]] - lg[ref[j]])) < 2e-2 * float(lg.abs().max()), (j, got, ref)
+
+
 @pytest.mark.parametrize("world", [2])
 def test_fused_k_sharded_decoder_two_ranks_rccl(world):
     """The multi-rank path for real (advisor, round 5): `world` processes, one GPU each, torch.distributed all_reduce = RCCL over xGMI --
