@@ -131,6 +131,48 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     }
 }
 
+// The LayerNorm that ends a BitLinearInf (bitnet.py:118-120) as its own pass over fp16 rows u [T, N] -- onebit_linear_forward without
+// ONEBIT_FLAG_SKIP_LN, i.e. the module path of a prefill call: y = fp16(LayerNorm(u)) (+ bias, rounded again).  Round 6: the row kernels'
+// form (packed halves in registers, ONE shifted-sum reduction, v_fma_mixlo) instead of ob_layernorm_rows_kernel's fp32 copy of the row
+// and two reductions: the module path of a [16384, 4096] -> 11008 call 1.235 -> 1.208 ms (tools/module_prefill_probe.py).  In place (y == u) is fine: every thread reads its elements and the pivot before the
+// reduction's barrier and writes after it.
+template <int NV, bool BIAS>
+__global__ __launch_bounds__(OB_DEC_THREADS) void ob_ln_rows_kernel(const _Float16 *uin, const _Float16 *__restrict__ bias, _Float16 *y, int N, float eps)
+{
+    __shared__ __attribute__((aligned(16))) float red[32];
+    const int tid = threadIdx.x;
+    const _Float16 *row = uin + (int64_t)blockIdx.x * N;
+    _Float16 *out = y + (int64_t)blockIdx.x * N;
+    ob_half8 u[NV], bv[BIAS ? NV : 1];
+    bool ok[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int base = (v * OB_DEC_THREADS + tid) * 8;
+        ok[v] = base < N;
+        u[v] = *reinterpret_cast<const ob_half8 *>(row + (ok[v] ? base : 0));
+        if (BIAS) bv[v] = *reinterpret_cast<const ob_half8 *>(bias + (ok[v] ? base : 0));
+    }
+    const float c0 = (float)row[0];
+    ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if (ok[v]) ob_stats8(u[v], c0, s2, q2);
+    float st[2] = {s2[0] + s2[1], q2[0] + q2[1]};
+    ob_block_sum_n<2, OB_DEC_WAVES>(st, red);
+    float mean, rstd;
+    ob_ln_stats(st[0], st[1], c0, N, eps, mean, rstd);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (!ok[v]) continue;
+        ob_half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = ob_ln_apply_h(u[v][i], rstd, nmr);
+        if (BIAS) o = o + bv[v];
+        *reinterpret_cast<ob_half8 *>(out + (v * OB_DEC_THREADS + tid) * 8) = o;
+    }
+}
+
 // u = fp16(fp16(z) * g) (bitnet.py:115-116) for up to three vectors of COMPLETE fp32 sums z (the all-reduced partials of
 // K-sharded projections: onebit_decode_step_ksharded), optionally with the per-16-row-tile LayerNorm partials (sum, M2) the
 // decode kernels' PST forms combine.  Block b covers 4096 elements of its segment; a tile is a pair of adjacent lanes.

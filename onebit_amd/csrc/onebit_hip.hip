@@ -447,6 +447,16 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             return ob_fail(ONEBIT_E_FLAG, "linear_forward: ONEBIT_FLAG_TILE_STATS on a call that did not take the LDS-DMA GEMM "
                                           "(workspace for the pre-scaled rows missing?)");
         if (skip && ubuf == y) return 0;
+        static const int ln_v3 = getenv("OB_LN_ROWS") ? atoi(getenv("OB_LN_ROWS")) : 1;           // A/B: 0 = ob_layernorm_rows_kernel
+        if (ln_v3 && !skip && T >= 64 && N % 8 == 0 && N <= OB_DEC_MAXV * OB_DEC_THREADS * 8 && ob_aligned(ubuf, 16) && (!bias || ob_aligned(bias, 16))) {
+            const _Float16 *ui = (const _Float16 *)ubuf, *bi = (const _Float16 *)bias;
+            const int nv = (int)((N + OB_DEC_THREADS * 8 - 1) / (OB_DEC_THREADS * 8));
+#define OB_LN_ROWS(NV_) do { if (bi) hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, true>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, ui, bi, (_Float16 *)y, (int)N, ln_eps); \
+                             else hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, false>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, ui, bi, (_Float16 *)y, (int)N, ln_eps); } while (0)
+            if (nv == 1) OB_LN_ROWS(1); else if (nv == 2) OB_LN_ROWS(2); else if (nv == 3) OB_LN_ROWS(3); else OB_LN_ROWS(4);
+#undef OB_LN_ROWS
+            return ob_launch_status("linear_forward(layernorm rows)");
+        }
         ob_launch_ln_f16<false>(nullptr, (const _Float16 *)ubuf, (const _Float16 *)g, (const _Float16 *)bias,
                                 (_Float16 *)y, nullptr, T, N, ln_eps, skip, s);
         return ob_launch_status("linear_forward(layernorm)");
