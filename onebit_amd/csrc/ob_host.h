@@ -58,6 +58,8 @@ OB_HIDDEN int ob_lm_head_argmax(const void *x, const void *lm_head, void *logits
 // u[i] = fp16(fp16(W_i . a_i) * g_i).  Returns ONEBIT_E_SHAPE when a projection is not eligible (the caller falls back to
 // onebit_linear_forward per projection).
 OB_HIDDEN int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s);
+// the projection's part of that eligibility (shape, pitch, the weights' alignment; rows assumed 16-byte aligned, 2 <= T <= 64)
+OB_HIDDEN bool ob_sk3_proj_ok(const onebit_proj_t &p);
 // up to three projections sharing T, K and the packed row pitch in ONE launch of the LDS-DMA prefill GEMM (ob_gemm3g_f16_kernel) on
 // their pre-scaled rows a[i] [T, K]: u[i] = fp16(fp16(W_i . a_i) * g_i).  ONEBIT_E_SHAPE when the group is not eligible (the caller
 // falls back to onebit_linear_forward per projection).

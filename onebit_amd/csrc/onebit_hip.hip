@@ -1656,6 +1656,11 @@ int ob_gemm3_ksplit2(const onebit_proj_t &p, const void *a, float *z0, float *z1
     return ob_launch_status("gemm3_ksplit2");
 }
 
+bool ob_sk3_proj_ok(const onebit_proj_t &p)
+{
+    return p.weight && p.weight_scale && ob_aligned(p.weight_scale, 16) && ob_skinny3_shape_ok(p.weight, p.ldw_bytes, nullptr, p.K, 64, p.K, p.N);
+}
+
 int ob_sk3_multi(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
 {
     if (np < 1 || np > 3) return ob_fail(ONEBIT_E_ARG, "sk3_multi: 1..3 projections");

@@ -270,6 +270,29 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         return onebit_linear_forward(p.weight, p.ldw_bytes, rows, p.input_factor, p.weight_scale, nullptr, u, nullptr, w.gemm_ws, w.gemm_ws_bytes,
                                      T, p.K, p.N, ONEBIT_F16, m->ln_eps, ONEBIT_FLAG_SKIP_LN | (prescaled ? ONEBIT_FLAG_PRESCALED : 0u), s);
     };
+    // 65 .. sk_rows rows: too few for the LDS-DMA GEMM's 256 x 128 tiles to fill the chip even grouped, and the round-1 kernels that took
+    // such calls run a 95-row step at 13B widths in 22.9 ms (a 543-row step: 20.5).  The LDS-DMA skinny GEMM in balanced passes of <= 64 rows
+    // re-reads the packed rows once per pass (40 MB per layer at 13B) and is still 1.5 - 2.7x faster: 95 rows 22.9 -> 8.6 ms, 159 rows 23.2 -> 11.9,
+    // 231 rows 21.8 -> 14.4, 287 rows 18.7 (grouped LDS-DMA GEMM) -> 17.6; 351 rows 18.9 vs 19.1: the grouped GEMM takes over (tools/midt_probe.py).
+    static const int sk_rows = getenv("OB_MIXED_SK_ROWS") ? atoi(getenv("OB_MIXED_SK_ROWS")) : 320;
+    bool sk_pass = T > 64 && T <= sk_rows;
+    for (int l = 0; sk_pass && l < m->n_layers; ++l) {
+        const onebit_layer_t &L = m->layers[l];
+        sk_pass = ob_sk3_proj_ok(L.q) && ob_sk3_proj_ok(L.k) && ob_sk3_proj_ok(L.v) && ob_sk3_proj_ok(L.o) && ob_sk3_proj_ok(L.gate) &&
+                  ob_sk3_proj_ok(L.up) && ob_sk3_proj_ok(L.down);
+    }
+    auto sk_passes = [&](const onebit_proj_t *const *ps, void *const *us, const _Float16 *const *as, int np) -> int {
+        const int nblk = (T + 63) / 64, rows = (T + nblk - 1) / nblk;
+        for (int r0 = 0; r0 < T; r0 += rows) {
+            const int n = std::min(rows, T - r0);
+            void *ub[3] = {nullptr, nullptr, nullptr};
+            const void *ab[3] = {nullptr, nullptr, nullptr};
+            for (int i = 0; i < np; ++i) { ub[i] = (_Float16 *)us[i] + (size_t)r0 * ps[i]->N; ab[i] = as[i] + (size_t)r0 * ps[i]->K; }
+            const int rc2 = ob_sk3_multi(ps, ub, ab, np, n, s);
+            if (rc2) return rc2;
+        }
+        return 0;
+    };
     // up to three projections sharing their input: ONE skinny launch when T <= 64, else one GEMM each
     auto gemm_group = [&](const onebit_proj_t *const *ps, void *const *us, const _Float16 *const *as, int np, bool prescaled) -> int {
         if (prescaled && T >= 2 && T <= 64) {
@@ -280,6 +303,7 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
             const void *av[3] = {as[0], as[np > 1 ? 1 : 0], as[np > 2 ? 2 : 0]};
             if (ob_gemm3_grouped(ps, us, av, np, T, s) == 0) return 0;
         }
+        if (prescaled && sk_pass) return sk_passes(ps, us, as, np);
         for (int i = 0; i < np; ++i) {
             const int rc2 = gemm(*ps[i], as[i], prescaled, us[i]);
             if (rc2) return rc2;
@@ -304,8 +328,8 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         // o_proj / down_proj (hidden-width outputs: half the tiles of a q|k|v group) that alone do not fill the chip run as two K-slices of
         // the same LDS-DMA GEMM; the row kernel that consumes them adds the slices (ks_prev: the previous layer's down_proj went that way)
         const bool ks_o = !pres_ok(L.o) && ob_gemm3_ksplit2_ok(L.o, T), ks_down = !pres_ok(L.down) && ob_gemm3_ksplit2_ok(L.down, T);
-        const bool pres_qkv = (pres_ok(L.q) && pres_ok(L.k) && pres_ok(L.v)) || grp_qkv, pres_o = pres_ok(L.o) || ks_o;
-        const bool pres_gu = (pres_ok(L.gate) && pres_ok(L.up)) || grp_gu, pres_down = pres_ok(L.down) || ks_down;
+        const bool pres_qkv = (pres_ok(L.q) && pres_ok(L.k) && pres_ok(L.v)) || grp_qkv || sk_pass, pres_o = pres_ok(L.o) || ks_o || sk_pass;
+        const bool pres_gu = (pres_ok(L.gate) && pres_ok(L.up)) || grp_gu || sk_pass, pres_down = pres_ok(L.down) || ks_down || sk_pass;
         // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm -> x, or the three consumers' pre-scaled rows
         ObRowsNormCall n1 = {};
         if (l == 0) { n1.embed = m->embed; n1.tokens = st->tokens; }
@@ -339,6 +363,8 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
             return rc;
         // 5. o_proj
         if (ks_o) { if ((rc = ob_gemm3_ksplit2(L.o, w.attn, w.z0, w.z1, T, s))) return rc; }
+        else if (sk_pass) { const onebit_proj_t *p1[3] = {&L.o, nullptr, nullptr}; void *u1[3] = {w.uo, nullptr, nullptr}; const _Float16 *a1[3] = {w.attn, nullptr, nullptr};
+                            if ((rc = sk_passes(p1, u1, a1, 1))) return rc; }
         else if ((rc = gemm(L.o, w.attn, pres_o, w.uo))) return rc;
         // 6. residual + LayerNorm(u_o) (+ o bias) + post-attention RMSNorm
         ObRowsNormCall n2 = {};
@@ -360,6 +386,8 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         }
         if ((rc = onebit_rows_swiglu(w.ug, w.uu, pres_down ? L.down.input_factor : nullptr, w.act, T, I, m->ln_eps, s))) return rc;
         if (ks_down) { if ((rc = ob_gemm3_ksplit2(L.down, w.act, w.z0, w.z1, T, s))) return rc; }
+        else if (sk_pass) { const onebit_proj_t *p1[3] = {&L.down, nullptr, nullptr}; void *u1[3] = {w.ud, nullptr, nullptr}; const _Float16 *a1[3] = {w.act, nullptr, nullptr};
+                            if ((rc = sk_passes(p1, u1, a1, 1))) return rc; }
         else if ((rc = gemm(L.down, w.act, pres_down, w.ud))) return rc;
         ks_prev = ks_down;
     }

@@ -265,11 +265,13 @@ def test_mixed_step_at_13b_widths_chunked_prompts_next_to_decoding_slots():
         assert out[rid] == ref or _near_tie(model, p, ref, out[rid], dev), rid
 
 
-@pytest.mark.parametrize("hidden,inter,heads,rows", [(5120, 13824, 40, 543), (5120, 13824, 40, 700), (4096, 11008, 32, 700)])
+@pytest.mark.parametrize("hidden,inter,heads,rows", [(5120, 13824, 40, 543), (5120, 13824, 40, 700), (4096, 11008, 32, 700),
+                                                     (5120, 13824, 40, 95), (5120, 13824, 40, 200), (4096, 11008, 32, 131), (4096, 11008, 32, 65)])
 def test_mixed_step_mid_size_routes(hidden, inter, heads, rows):
     """A few hundred rows at 13B / 7B widths (7B down_proj: K = 11008 splits into 5632 + 5376): q|k|v and gate|up take pre-scaled rows because the GROUP fills the chip (ob_gemm3_group_ok),
-    o_proj / down_proj run as two K-slices whose fp32 sums the next row kernel adds (ob_gemm3_ksplit2).  Logits of the prompt's last row
-    and of the decode rows against the module path."""
+    o_proj / down_proj run as two K-slices whose fp32 sums the next row kernel adds (ob_gemm3_ksplit2); 65 .. 320 rows: every projection
+    as balanced passes of <= 64 rows through the LDS-DMA skinny GEMM.  Logits of the prompt's last row and of the decode rows against
+    the module path."""
     from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
     from onebit_amd.engine import MixedStep
     dev = torch.device(DEV)
