@@ -608,6 +608,37 @@ def measure_decode_ctx(model, dev, contexts=(512, 2000), slots=32, slot_ctx=512,
     return {"single_stream": one, "batched": bat, "per": "GPU", "data": "synthetic (random K / V rows)"}
 
 
+def measure_ttft(model, dev, prompts=(16, 128, 512, 2000)):
+    """Time to first token of ONE request: DecodeEngine.prime (the prompt through onebit_mixed_step: one C call, lm_head on the last row)
+    beside DecodeEngine.prefill (module path with the fused glue, logits of every row); wall clock around call + device sync, median of 5."""
+    from onebit_amd.engine import DecodeEngine
+    cfg = model.config
+    max_len = min(cfg.max_position_embeddings, max(prompts) + 48)
+    eng = DecodeEngine(model, max_len=max_len)
+    g = torch.Generator().manual_seed(3)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(dev); ts.append(time.perf_counter() - t0)
+        return round(sorted(ts)[2] * 1e3, 3)
+
+    res = {"engine": "DecodeEngine.prime = onebit_mixed_step over the prompt rows", "per_prompt": []}
+    for S in prompts:
+        S = min(S, max_len - 8)
+        ids = torch.randint(0, cfg.vocab_size, (1, S), generator=g).to(dev)
+        native = timed(lambda: eng.prime(ids))
+        first = eng.first_token
+        module = timed(lambda: eng.prefill(ids))
+        res["per_prompt"].append({"prompt_tokens": S, "ms": native, "prompt_tokens_per_s": round(S / native * 1e3, 1), "module_path_ms": module,
+                                  "first_token_equal": bool(first == eng.first_token)})
+    del eng
+    return res
+
+
 def measure_prefill_model(model, dev, B=8, S=2048):
     """BASELINE configs[2]: whole-model prefill of B x S tokens (1-bit GEMMs + fused row glue +
     the vendor's fused attention), tokens/s and the 1-bit layers' share expressed in TFLOP/s."""
@@ -917,6 +948,7 @@ class Hooks:
     measure_mixed_step = staticmethod(measure_mixed_step)
     measure_decode_ctx = staticmethod(measure_decode_ctx)
     measure_prefill_model = staticmethod(measure_prefill_model)
+    measure_ttft = staticmethod(measure_ttft)
     measure_prefill_model_tp = staticmethod(measure_prefill_model_tp)
     measure_k_sharded_decode = staticmethod(measure_k_sharded_decode)
     measure_cpu_baseline = staticmethod(measure_cpu_baseline)
@@ -1044,6 +1076,8 @@ def main(argv=None, hooks=None):
         serve = leg("continuous_batch", lambda: hk.measure_continuous_batch(model, dev))
     if not args.no_prefill:
         leg("prefill_model", lambda: hk.measure_prefill_model(model, dev))
+        if hasattr(hk, "measure_ttft"):
+            leg("time_to_first_token", lambda: hk.measure_ttft(model, dev))
     if not args.no_eval:                        # the evaluation callers at their real shape
         leg("eval_ppl", lambda: hk.measure_eval(model, dev))
     if not args.no_train:                       # the train-mode layer

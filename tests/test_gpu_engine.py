@@ -525,3 +525,43 @@ def test_attn_blind_hint_does_not_change_results():
     with pytest.raises(Exception, match="attn_blind"):
         eng._launch(blind64=True)
     eng._state64.attn_blind = 64
+
+
+@pytest.mark.parametrize("cfgkw,S,rows", [
+    (dict(vocab_size=512, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=512), 150, 2048),
+    (dict(vocab_size=512, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=512), 150, 64),
+    (dict(vocab_size=640, hidden_size=1024, intermediate_size=2816, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+          max_position_embeddings=512), 333, 128),
+    (dict(vocab_size=512, hidden_size=512, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=256,
+          attention_bias=True), 1, 2048),
+])
+def test_engine_prime_is_the_native_prefill(golden_dir, cfgkw, S, rows):
+    """DecodeEngine.prime (round 6): the prompt through onebit_mixed_step -- whole, in chunks of `rows` tokens (64 / 128: chunks with past),
+    a one-token prompt -- against DecodeEngine.prefill (module path): K / V cache rows equal to 2^-9 relative, the first token and the
+    following greedy tokens equal up to a near-tie of the module path's logits; generate() takes the native route (asserted)."""
+    from onebit_amd.engine import DecodeEngine
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(**cfgkw)
+    model = build_synthetic_model(cfg, seed=41, device=dev)
+    ids = torch.randint(0, cfg.vocab_size, (1, S), generator=torch.Generator().manual_seed(S)).to(dev)
+    max_len = S + 12
+    ref_eng = DecodeEngine(model, max_len=max_len, native_prefill=False)
+    eng = DecodeEngine(model, max_len=max_len, prefill_rows=rows)
+    lg = ref_eng.prefill(ids)[0, -1].float()
+    first = eng.prime(ids)
+    torch.cuda.synchronize()
+    assert eng._mixed is not None and eng._mixed.launches == -(-S // max(rows, 64))
+    scale = float(lg.abs().max())
+    assert first == ref_eng.first_token or abs(float(lg[first] - lg[ref_eng.first_token])) < 2e-2 * scale
+    for (ka, va), (kb, vb) in zip(eng.cache.layers, ref_eng.cache.layers):
+        for a, b in ((ka, kb), (va, vb)):
+            a, b = a[0, :, :S].float(), b[0, :, :S].float()
+            assert float((a - b).abs().max()) <= 2.0 ** -8 * max(float(b.abs().max()), 1.0)
+    got = eng.generate(ids, 10)[0, S:].tolist()
+    ref = ref_eng.generate(ids, 10)[0, S:].tolist()
+    assert ref_eng._mixed is None and len(got) == 10
+    if got != ref:
+        j = next(i for i in range(10) if got[i] != ref[i])
+        l2 = model(torch.tensor([ids[0].tolist() + ref[:j]], device=dev))[0, -1].float()
+        assert abs(float(l2[got[j]] - l2[ref[j]])) < 2e-2 * float(l2.abs().max()), (j, got, ref)
