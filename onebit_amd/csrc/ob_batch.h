@@ -33,6 +33,7 @@ struct ObBNormArgs {
                                   //   r = hres_in + fp16(LayerNorm(u_prev) + bias_prev)  (bitnet.py:119-120, then :912)
     // (appended in round 6) optional [grid]: workgroup t READS row rows[t] of hres_in / u_prev and writes row t of the outputs --
     const int *rows;              //   the final norm of a mixed step on the rows whose logits are wanted (onebit_mixed_step)
+    const float *z2, *z3;         // optional third / fourth partial sum beside z0, z1 (K-slices: ob_gemm3_ksplit)
 };
 
 // NV = 8-half vectors per thread actually populated: ceil(H / 4096).  (Sized OB_DEC_MAXV = 4 for every width, a 4096-wide
@@ -71,9 +72,12 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
                     const ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z0 + rin + b0 + 4 * q);
                     // (z1 == NULL: one complete sum, the all-reduced partials of a K-sharded projection -- uniform test)
                     const ob_float4 b = A.z1 ? *reinterpret_cast<const ob_float4 *>(A.z1 + rin + b0 + 4 * q) : (ob_float4){0.f, 0.f, 0.f, 0.f};
+                    ob_float4 ab = a + b;
+                    if (A.z2) ab = ab + *reinterpret_cast<const ob_float4 *>(A.z2 + rin + b0 + 4 * q);
+                    if (A.z3) ab = ab + *reinterpret_cast<const ob_float4 *>(A.z3 + rin + b0 + 4 * q);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        uv[v][4 * q + i] = (_Float16)(ob_round_h(a[i] + b[i]) * (float)gv[4 * q + i]);
+                        uv[v][4 * q + i] = (_Float16)(ob_round_h(ab[i]) * (float)gv[4 * q + i]);
                 }
             }
         }
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
     if (!EMBED) {
         // pivot of the shifted sums = element 0 of the row, the same value in every thread
         const float c0 = A.u_prev ? (float)A.u_prev[rin]
-                                  : (float)(_Float16)(ob_round_h(A.z0[rin] + (A.z1 ? A.z1[rin] : 0.f)) * (float)A.g_prev[0]);
+                                  : (float)(_Float16)(ob_round_h(((A.z0[rin] + (A.z1 ? A.z1[rin] : 0.f)) + (A.z2 ? A.z2[rin] : 0.f)) + (A.z3 ? A.z3[rin] : 0.f)) * (float)A.g_prev[0]);
         ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
         for (int v = 0; v < NV; ++v)

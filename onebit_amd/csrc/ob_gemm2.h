@@ -569,10 +569,8 @@ struct ObG3Group {
     int N[3], nbn[3], tile_end[3];
     long long ldw_words, lda;
     int T, K;
-    float *zp[3];                 // PARTIAL instances: fp32 sums [T, N] per problem (K-slices of ONE projection: W / a advanced to the slice)
-    int Ks[3];                    //   and each slice's own length (multiples of 256)
 };
-template <int WT, bool PARTIAL = false>
+template <int WT>
 __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3g_f16_kernel(const ObG3Group G)
 {
     const int bid = ob_g3_bid();
@@ -582,11 +580,32 @@ __global__ __launch_bounds__(256 * WT, 2) void ob_gemm3g_f16_kernel(const ObG3Gr
     const _Float16 *a = p == 0 ? G.a[0] : (p == 1 ? G.a[1] : G.a[2]);
     const _Float16 *g = p == 0 ? G.g[0] : (p == 1 ? G.g[1] : G.g[2]);
     _Float16 *u = p == 0 ? G.u[0] : (p == 1 ? G.u[1] : G.u[2]);
-    float *zp = PARTIAL ? (p == 0 ? G.zp[0] : (p == 1 ? G.zp[1] : G.zp[2])) : nullptr;
     const int N = p == 0 ? G.N[0] : (p == 1 ? G.N[1] : G.N[2]);
     const int nbn = p == 0 ? G.nbn[0] : (p == 1 ? G.nbn[1] : G.nbn[2]);
-    const int K = PARTIAL ? (p == 0 ? G.Ks[0] : (p == 1 ? G.Ks[1] : G.Ks[2])) : G.K;
-    ob_gemm3_body<PARTIAL, WT>(W, G.ldw_words, a, G.lda, g, u, zp, G.T, K, N, nbn, bid - b0);
+    ob_gemm3_body<false, WT>(W, G.ldw_words, a, G.lda, g, u, nullptr, G.T, G.K, N, nbn, bid - b0);
+}
+
+// K-SLICED form (round 6): ONE projection whose 256 x 128 tiles alone leave most of the chip idle (hidden-width outputs at a few hundred
+// token rows: o_proj / down_proj of a mid-size prefill or mixed step) as `ns` <= 4 K-slices in one launch -- slice j = tiles
+// [j * tiles, (j + 1) * tiles) multiplies quads [q0_j, q0_j + nq_j) of K (a quad = 256 columns = 4 K steps; the longer slices first) and
+// stores its fp32 sums to z[j] [T, N].  The row kernel that consumes the projection adds the slices and applies fp16(fp16(.) * g)
+// (bitnet.py:115-116) to the complete sum.  ns times the workgroups, each with 1 / ns of the K loop: a round of workgroups at K = 4096 takes
+// ~100 us whatever the fill, so 48 tiles x 4 slices finish in a quarter of the time of 48 tiles.
+struct ObG3Slices {
+    const uint32_t *W; const _Float16 *a; float *z[4];
+    long long ldw_words, lda;
+    int T, N, nbn, tiles, ns, quads;
+};
+template <int WT>
+__global__ __launch_bounds__(256 * WT, 2) void ob_gemm3ks_f16_kernel(const ObG3Slices G)
+{
+    const int bid = ob_g3_bid();
+    const int j = bid / G.tiles;
+    const int qb = G.quads / G.ns, qr = G.quads - qb * G.ns;
+    const int q0 = j * qb + min(j, qr), nq = qb + (j < qr ? 1 : 0);
+    float *zp = j == 0 ? G.z[0] : (j == 1 ? G.z[1] : (j == 2 ? G.z[2] : G.z[3]));
+    ob_gemm3_body<true, WT>(G.W + q0 * (4 * OB_G2_K / 32), G.ldw_words, G.a + q0 * (4 * OB_G2_K), G.lda, nullptr, nullptr, zp, G.T,
+                            nq * (4 * OB_G2_K), G.N, G.nbn, bid - j * G.tiles);
 }
 #undef RN
 #undef RT

@@ -46,9 +46,10 @@ struct ObRowsNormCall {
     const void *h_next[3]; void *x_scaled[3]; int n_scaled;
     const int32_t *rows;
     int64_t T; int H; float rms_eps, ln_eps;
-    // instead of u_prev: the previous projection as two K-slices' fp32 sums (ob_gemm3_ksplit2) + its weight_scale:
-    // u = fp16(fp16(z0 + z1) * g_prev) (bitnet.py:115-116) is formed by the row kernel
+    // instead of u_prev: the previous projection as up to four K-slices' fp32 sums (ob_gemm3_ksplit) + its weight_scale:
+    // u = fp16(fp16(z0 + z1 (+ z2 (+ z3))) * g_prev) (bitnet.py:115-116) is formed by the row kernel
     const float *z0, *z1; const void *g_prev;
+    const float *z2, *z3;
 };
 OB_HIDDEN int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s);
 // fp16 lm_head for B <= 64 rows + greedy token per row (ob_b_lmhead_kernel + ob_b_argmax_kernel)
@@ -67,8 +68,9 @@ OB_HIDDEN int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, 
 // the eligibility test of ob_gemm3_grouped alone (shapes, pitches, the weights' alignment, the GROUP's tile count against the CU count;
 // rows / outputs assumed 16-byte aligned): a caller that is about to choose between pre-scaled rows for the group and plain rows asks first
 OB_HIDDEN bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T);
-// ONE projection on its pre-scaled rows a [T, K] as TWO K-slices in one launch of the LDS-DMA GEMM (fp32 sums z0, z1 [T, N], added and
+// ONE projection on its pre-scaled rows a [T, K] as two to four K-slices in one launch of the LDS-DMA GEMM (fp32 sums z[i] [T, N], added and
 // scaled by the consuming row kernel): a hidden-width projection at a few hundred rows has too few 256 x 128 tiles for the chip (13B, 543 rows:
-// 100), its two halves have twice as many.  ob_gemm3_ksplit2_ok: the projection alone is NOT eligible for the LDS-DMA GEMM, its halves are.
-OB_HIDDEN bool ob_gemm3_ksplit2_ok(const onebit_proj_t &p, int64_t T);
-OB_HIDDEN int ob_gemm3_ksplit2(const onebit_proj_t &p, const void *a, float *z0, float *z1, int64_t T, hipStream_t s);
+// 100), its slices have that many times more.  ob_gemm3_ksplit_n: 0 when the projection alone is eligible for the LDS-DMA GEMM or no
+// slicing fills two thirds of the CUs, else the number of slices (the fewest that do).
+OB_HIDDEN int ob_gemm3_ksplit_n(const onebit_proj_t &p, int64_t T);
+OB_HIDDEN int ob_gemm3_ksplit(const onebit_proj_t &p, const void *a, float *const *z, int ns, int64_t T, hipStream_t s);

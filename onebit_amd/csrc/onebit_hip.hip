@@ -1559,7 +1559,7 @@ int ob_rows_norm(const ObRowsNormCall &c, hipStream_t s)
     a.embed = (const _Float16 *)c.embed; a.tokens = c.tokens; a.hres_in = (const _Float16 *)c.hres_in; a.u_prev = (const _Float16 *)c.u_prev;
     a.bias_prev = (const _Float16 *)c.bias_prev; a.rms_w = (const _Float16 *)c.rms_w; a.hres_out = (_Float16 *)c.hres_out; a.x = (_Float16 *)c.x;
     a.H = c.H; a.rms_eps = c.rms_eps; a.ln_eps = c.ln_eps; a.n_scaled = c.n_scaled; a.rows = c.rows;
-    if (!c.embed && !c.u_prev) { a.z0 = c.z0; a.z1 = c.z1; a.g_prev = (const _Float16 *)c.g_prev; }
+    if (!c.embed && !c.u_prev) { a.z0 = c.z0; a.z1 = c.z1; a.z2 = c.z2; a.z3 = c.z3; a.g_prev = (const _Float16 *)c.g_prev; }
     for (int i = 0; i < c.n_scaled; ++i) {
         if (!c.h_next[i] || !c.x_scaled[i]) return ob_fail(ONEBIT_E_ARG, "rows_norm: null scaled output %d", i);
         a.h_next[i] = (const _Float16 *)c.h_next[i]; a.x_scaled[i] = (_Float16 *)c.x_scaled[i];
@@ -1584,7 +1584,9 @@ bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T)
             return false;
         tiles += ((p.N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
     }
-    return 3 * tiles >= 2 * (int64_t)ob_cu_count() && tiles <= 0x3fffffff;
+    // a GROUP is worth one launch from half a round of workgroups on: the alternative is one launch of the round-1 kernel per member
+    static const int grp_den = getenv("OB_GEMM3_GROUP_DEN") ? atoi(getenv("OB_GEMM3_GROUP_DEN")) : 2;
+    return tiles * std::max(grp_den, 1) >= (int64_t)ob_cu_count() && tiles <= 0x3fffffff;
 }
 
 int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
@@ -1610,7 +1612,7 @@ int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void
         G.W[i] = (const uint32_t *)p.weight; G.a[i] = (const _Float16 *)as[j]; G.g[i] = (const _Float16 *)p.weight_scale; G.u[i] = (_Float16 *)us[j];
         G.N[i] = (int)p.N; G.tile_end[i] = (int)tiles;
     }
-    if (3 * tiles < 2 * (int64_t)ob_cu_count() || tiles > 0x3fffffff) return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: grid too small / large");
+    if (!ob_gemm3_group_ok(ps, np, T)) return ob_fail(ONEBIT_E_SHAPE, "gemm3_grouped: grid too small / large");
     G.ldw_words = ldw / 4; G.lda = K; G.T = (int)T; G.K = (int)K;
     static const int g4_env = getenv("OB_GEMM4") ? atoi(getenv("OB_GEMM4")) : OB_GEMM4_DEFAULT;
     if (g4_env) {
@@ -1625,35 +1627,39 @@ int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void
     return ob_launch_status("gemm3_grouped");
 }
 
-bool ob_gemm3_ksplit2_ok(const onebit_proj_t &p, int64_t T)
+int ob_gemm3_ksplit_n(const onebit_proj_t &p, int64_t T)
 {
-    static const int env = getenv("OB_GEMM3_KSPLIT") ? atoi(getenv("OB_GEMM3_KSPLIT")) : 1;         // A/B: 0 = the 128 x 128 kernel on plain rows
+    static const int env = getenv("OB_GEMM3_KSPLIT") ? atoi(getenv("OB_GEMM3_KSPLIT")) : 4;         // A/B: 0 = off, 2 .. 4 = that many slices at most
     static const int env3 = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
-    if (!env || !env3 || T < 192 || p.K % (4 * OB_G2_K) != 0 || p.K < 8 * OB_G2_K || p.N % 4 != 0 || T * p.K * 2 >= ((int64_t)1 << 32) || p.ldw_bytes % 16 != 0 ||
+    // a projection with fewer tiles than this is sliced (default: what the unsliced LDS-DMA GEMM asks for, two thirds of the CUs)
+    static const int tiles_env = getenv("OB_GEMM3_KSPLIT_TILES") ? atoi(getenv("OB_GEMM3_KSPLIT_TILES")) : 0;
+    if (env < 2 || !env3 || T < 192 || p.K % (4 * OB_G2_K) != 0 || p.N % 4 != 0 || T * p.K * 2 >= ((int64_t)1 << 32) || p.ldw_bytes % 16 != 0 ||
         p.N * p.ldw_bytes >= ((int64_t)1 << 32) || !p.weight || !p.weight_scale || !ob_aligned(p.weight, 16) || !ob_aligned(p.weight_scale, 16))
-        return false;
+        return 0;
     const int64_t tiles = ((p.N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
     const int64_t cus = ob_cu_count();
-    return 3 * tiles < 2 * cus && 3 * 2 * tiles >= 2 * cus;          // not eligible alone, eligible as two slices
+    if (tiles_env ? tiles >= tiles_env : 3 * tiles >= 2 * cus) return 0;      // enough tiles alone
+    // as many slices as leave each at least four quads (1024 columns) of K loop: the shorter the loop, the shorter the one round
+    const int quads = (int)(p.K / (4 * OB_G2_K));
+    const int ns = std::min(std::min(env, 4), quads / 4);
+    return ns >= 2 ? ns : 0;
 }
 
-int ob_gemm3_ksplit2(const onebit_proj_t &p, const void *a, float *z0, float *z1, int64_t T, hipStream_t s)
+int ob_gemm3_ksplit(const onebit_proj_t &p, const void *a, float *const *z, int ns, int64_t T, hipStream_t s)
 {
-    if (!ob_gemm3_ksplit2_ok(p, T) || !a || !z0 || !z1 || !ob_aligned(a, 16) || !ob_aligned(z0, 16) || !ob_aligned(z1, 16))
-        return ob_fail(ONEBIT_E_SHAPE, "gemm3_ksplit2: not eligible");
-    const int64_t Kh = (p.K / (4 * OB_G2_K) + 1) / 2 * (4 * OB_G2_K);          // slices of whole 256-element quads: 7B down_proj 11008 = 5632 + 5376
-    ObG3Group G = {};
-    const int nbn = (int)((p.N + OB_G2_N - 1) / OB_G2_N), nbt = (int)((T + 127) / 128);
-    for (int i = 0; i < 3; ++i) {
-        const int j = i < 2 ? i : 1;
-        G.W[i] = (const uint32_t *)p.weight + j * (Kh / 32); G.a[i] = (const _Float16 *)a + j * Kh; G.g[i] = nullptr; G.u[i] = nullptr;
-        G.zp[i] = j == 0 ? z0 : z1; G.Ks[i] = (int)(j == 0 ? Kh : p.K - Kh); G.N[i] = (int)p.N; G.nbn[i] = nbn; G.tile_end[i] = nbn * nbt * (j + 1);
+    if (ns < 2 || ns > 4 || ns != ob_gemm3_ksplit_n(p, T) || !a || !z || !ob_aligned(a, 16))
+        return ob_fail(ONEBIT_E_SHAPE, "gemm3_ksplit: not eligible");
+    ObG3Slices G = {};
+    for (int i = 0; i < 4; ++i) {
+        G.z[i] = z[i < ns ? i : ns - 1];
+        if (!G.z[i] || !ob_aligned(G.z[i], 16)) return ob_fail(ONEBIT_E_ALIGN, "gemm3_ksplit: partial sums must be 16-byte aligned");
     }
-    G.ldw_words = p.ldw_bytes / 4; G.lda = p.K; G.T = (int)T; G.K = (int)Kh;
+    G.W = (const uint32_t *)p.weight; G.a = (const _Float16 *)a; G.ldw_words = p.ldw_bytes / 4; G.lda = p.K; G.T = (int)T; G.N = (int)p.N;
+    G.nbn = (int)((p.N + OB_G2_N - 1) / OB_G2_N); G.tiles = G.nbn * (int)((T + 127) / 128); G.ns = ns; G.quads = (int)(p.K / (4 * OB_G2_K));
     static bool attr_set[OB_MAX_DEVICES] = {};
-    ob_set_max_lds_once(ob_gemm3g_f16_kernel<1, true>, attr_set, OB_G3_LDS_W(1));
-    hipLaunchKernelGGL((ob_gemm3g_f16_kernel<1, true>), dim3((unsigned)(2 * nbn * nbt)), dim3(256), OB_G3_LDS_W(1), s, G);
-    return ob_launch_status("gemm3_ksplit2");
+    ob_set_max_lds_once(ob_gemm3ks_f16_kernel<1>, attr_set, OB_G3_LDS_W(1));
+    hipLaunchKernelGGL((ob_gemm3ks_f16_kernel<1>), dim3((unsigned)(ns * G.tiles)), dim3(256), OB_G3_LDS_W(1), s, G);
+    return ob_launch_status("gemm3_ksplit");
 }
 
 bool ob_sk3_proj_ok(const onebit_proj_t &p)

@@ -176,7 +176,7 @@ struct ObMixedWs {
     _Float16 *hA, *hB, *x, *xs[3], *uq, *uk, *uv, *q, *attn, *uo, *ug, *uu, *act, *ud, *xh;
     char *gemm_ws; size_t gemm_ws_bytes;
     char *attn_scratch; size_t attn_scratch_bytes;
-    float *z0, *z1;               // K-slice sums [rows, hidden] of o_proj / down_proj at a few hundred rows (ob_gemm3_ksplit2)
+    float *z[4];                  // K-slice sums [rows, hidden] of o_proj / down_proj at a few hundred rows (ob_gemm3_ksplit)
     size_t total;
 };
 #define OB_MIXED_MAX_OUT 64          // rows per lm_head launch
@@ -209,7 +209,7 @@ static ObMixedWs ob_mixed_carve(const onebit_model_t *m, int64_t rows, int dec_r
     w.ud = (_Float16 *)take(T * H * 2); w.xh = (_Float16 *)take((size_t)OB_MIXED_MAX_OUT * H * 2);
     w.gemm_ws_bytes = T * std::max(std::max(H, I), NQ) * 2;
     w.gemm_ws = take(w.gemm_ws_bytes);
-    w.z0 = (float *)take(T * H * 4); w.z1 = (float *)take(T * H * 4);
+    for (int i = 0; i < 4; ++i) w.z[i] = (float *)take(T * H * 4);
     w.total = off;
     return w;
 }
@@ -310,7 +310,7 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         }
         return 0;
     };
-    bool ks_prev = false;
+    int ks_prev = 0;
     for (int l = 0; l < m->n_layers; ++l) {
         const onebit_layer_t &L = m->layers[l];
         if (!L.input_layernorm_w || !L.post_attention_layernorm_w || !L.k_cache || !L.v_cache)
@@ -327,13 +327,13 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         const bool grp_qkv = ob_gemm3_group_ok(g_qkv, 3, T), grp_gu = ob_gemm3_group_ok(g_gu, 2, T);
         // o_proj / down_proj (hidden-width outputs: half the tiles of a q|k|v group) that alone do not fill the chip run as two K-slices of
         // the same LDS-DMA GEMM; the row kernel that consumes them adds the slices (ks_prev: the previous layer's down_proj went that way)
-        const bool ks_o = !pres_ok(L.o) && ob_gemm3_ksplit2_ok(L.o, T), ks_down = !pres_ok(L.down) && ob_gemm3_ksplit2_ok(L.down, T);
-        const bool pres_qkv = (pres_ok(L.q) && pres_ok(L.k) && pres_ok(L.v)) || grp_qkv || sk_pass, pres_o = pres_ok(L.o) || ks_o || sk_pass;
-        const bool pres_gu = (pres_ok(L.gate) && pres_ok(L.up)) || grp_gu || sk_pass, pres_down = pres_ok(L.down) || ks_down || sk_pass;
+        const int ks_o = pres_ok(L.o) ? 0 : ob_gemm3_ksplit_n(L.o, T), ks_down = pres_ok(L.down) ? 0 : ob_gemm3_ksplit_n(L.down, T);
+        const bool pres_qkv = (pres_ok(L.q) && pres_ok(L.k) && pres_ok(L.v)) || grp_qkv || sk_pass, pres_o = pres_ok(L.o) || ks_o > 0 || sk_pass;
+        const bool pres_gu = (pres_ok(L.gate) && pres_ok(L.up)) || grp_gu || sk_pass, pres_down = pres_ok(L.down) || ks_down > 0 || sk_pass;
         // 1. residual (+ LayerNorm of the previous down_proj) + input RMSNorm -> x, or the three consumers' pre-scaled rows
         ObRowsNormCall n1 = {};
         if (l == 0) { n1.embed = m->embed; n1.tokens = st->tokens; }
-        else if (ks_prev) { n1.hres_in = w.hA; n1.z0 = w.z0; n1.z1 = w.z1; n1.g_prev = m->layers[l - 1].down.weight_scale; }
+        else if (ks_prev) { n1.hres_in = w.hA; n1.z0 = w.z[0]; n1.z1 = w.z[1]; n1.z2 = ks_prev > 2 ? w.z[2] : nullptr; n1.z3 = ks_prev > 3 ? w.z[3] : nullptr; n1.g_prev = m->layers[l - 1].down.weight_scale; }
         else { n1.hres_in = w.hA; n1.u_prev = w.ud; }
         n1.rms_w = L.input_layernorm_w; n1.hres_out = w.hB; n1.T = T; n1.H = H; n1.rms_eps = m->rms_eps; n1.ln_eps = m->ln_eps;
         if (pres_qkv) {
@@ -362,14 +362,14 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
                                            m->n_heads, m->n_kv_heads, D, st->n_slots, m->max_len, chunk, nsplit, w.attn_scratch, s)))
             return rc;
         // 5. o_proj
-        if (ks_o) { if ((rc = ob_gemm3_ksplit2(L.o, w.attn, w.z0, w.z1, T, s))) return rc; }
+        if (ks_o) { if ((rc = ob_gemm3_ksplit(L.o, w.attn, w.z, ks_o, T, s))) return rc; }
         else if (sk_pass) { const onebit_proj_t *p1[3] = {&L.o, nullptr, nullptr}; void *u1[3] = {w.uo, nullptr, nullptr}; const _Float16 *a1[3] = {w.attn, nullptr, nullptr};
                             if ((rc = sk_passes(p1, u1, a1, 1))) return rc; }
         else if ((rc = gemm(L.o, w.attn, pres_o, w.uo))) return rc;
         // 6. residual + LayerNorm(u_o) (+ o bias) + post-attention RMSNorm
         ObRowsNormCall n2 = {};
         n2.hres_in = w.hB; n2.bias_prev = L.o_bias;
-        if (ks_o) { n2.z0 = w.z0; n2.z1 = w.z1; n2.g_prev = L.o.weight_scale; } else n2.u_prev = w.uo;
+        if (ks_o) { n2.z0 = w.z[0]; n2.z1 = w.z[1]; n2.z2 = ks_o > 2 ? w.z[2] : nullptr; n2.z3 = ks_o > 3 ? w.z[3] : nullptr; n2.g_prev = L.o.weight_scale; } else n2.u_prev = w.uo;
         n2.rms_w = L.post_attention_layernorm_w; n2.hres_out = w.hA;
         n2.T = T; n2.H = H; n2.rms_eps = m->rms_eps; n2.ln_eps = m->ln_eps;
         if (pres_gu) {
@@ -385,7 +385,7 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
             if ((rc = gemm_group(ps, us, as, 2, pres_gu))) return rc;
         }
         if ((rc = onebit_rows_swiglu(w.ug, w.uu, pres_down ? L.down.input_factor : nullptr, w.act, T, I, m->ln_eps, s))) return rc;
-        if (ks_down) { if ((rc = ob_gemm3_ksplit2(L.down, w.act, w.z0, w.z1, T, s))) return rc; }
+        if (ks_down) { if ((rc = ob_gemm3_ksplit(L.down, w.act, w.z, ks_down, T, s))) return rc; }
         else if (sk_pass) { const onebit_proj_t *p1[3] = {&L.down, nullptr, nullptr}; void *u1[3] = {w.ud, nullptr, nullptr}; const _Float16 *a1[3] = {w.act, nullptr, nullptr};
                             if ((rc = sk_passes(p1, u1, a1, 1))) return rc; }
         else if ((rc = gemm(L.down, w.act, pres_down, w.ud))) return rc;
@@ -396,7 +396,7 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         const int no = std::min(NO - o0, OB_MIXED_MAX_OUT);
         ObRowsNormCall nf = {};
         nf.hres_in = w.hA; nf.rms_w = m->final_norm_w;
-        if (ks_prev) { nf.z0 = w.z0; nf.z1 = w.z1; nf.g_prev = m->layers[m->n_layers - 1].down.weight_scale; } else nf.u_prev = w.ud;
+        if (ks_prev) { nf.z0 = w.z[0]; nf.z1 = w.z[1]; nf.z2 = ks_prev > 2 ? w.z[2] : nullptr; nf.z3 = ks_prev > 3 ? w.z[3] : nullptr; nf.g_prev = m->layers[m->n_layers - 1].down.weight_scale; } else nf.u_prev = w.ud;
         nf.hres_out = w.hB;      // (hB rows 0 .. no - 1: scratch here)
         nf.x = w.xh; nf.rows = st->out_rows + o0; nf.T = no; nf.H = H; nf.rms_eps = m->rms_eps; nf.ln_eps = m->ln_eps;
         if ((rc = ob_rows_norm(nf, s))) return rc;
