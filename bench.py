@@ -730,7 +730,14 @@ def measure_eval(model, dev, windows=8, seqlen=2048, requests=32):
             ppl = perplexity(model, stream, seqlen, logits_dtype=torch.float16)
             torch.cuda.synchronize(dev)
             dt_p = time.perf_counter() - t0
-            loglikelihood_tokens(model, reqs[:4], batch_size=requests, max_length=seqlen)
+            loglikelihood_tokens(model, reqs[:4], batch_size=requests, max_length=seqlen, ragged=False)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            res_pad = loglikelihood_tokens(model, reqs, batch_size=requests, max_length=seqlen, ragged=False)
+            torch.cuda.synchronize(dev)
+            dt_pad = time.perf_counter() - t0
+            # the default route: one onebit_mixed_step over the REAL token rows of the batch, lm_head on the continuation rows
+            loglikelihood_tokens(model, reqs, batch_size=requests, max_length=seqlen)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             res = loglikelihood_tokens(model, reqs, batch_size=requests, max_length=seqlen)
@@ -740,13 +747,18 @@ def measure_eval(model, dev, windows=8, seqlen=2048, requests=32):
         model.set_attention("eager").set_fused_glue(False)
         torch.cuda.empty_cache()
     pad_to = max(len(c) + len(t) - 1 for c, t in reqs)
+    real_rows = sum(len(c) + len(t) - 1 for c, t in reqs)
     return {"perplexity": {"windows": windows, "seqlen": seqlen, "ms_per_window": round(dt_p / windows * 1e3, 2),
                            "tokens_per_s": round(windows * seqlen / dt_p, 1), "ppl_synthetic": round(ppl, 1),
                            "gemm_routes": routes(seqlen), "logits": "fp16 [1, %d, %d] per window, loss in fp16 (lm_eval.py:104-121)" % (seqlen, cfg.vocab_size)},
             "loglikelihood_tokens": {"requests": requests, "lengths": "%d..%d tokens" % (min(lens), max(lens)), "padded_batch": [requests, pad_to],
-                                     "ms": round(dt_l * 1e3, 1), "tokens_per_s_padded": round(requests * pad_to / dt_l, 1),
-                                     "tokens_per_s_real": round(sum(len(c) + len(t) - 1 for c, t in reqs) / dt_l, 1),
-                                     "gemm_routes": routes(requests * pad_to), "finite": bool(all(v[0] == v[0] for v in res)),
+                                     "real_rows": real_rows, "ms": round(dt_l * 1e3, 1), "tokens_per_s_real": round(real_rows / dt_l, 1),
+                                     "route": "ragged: ONE onebit_mixed_step over the real token rows (no right-padding), lm_head on the continuation rows",
+                                     "padded_route": {"ms": round(dt_pad * 1e3, 1), "tokens_per_s_padded": round(requests * pad_to / dt_pad, 1),
+                                                      "tokens_per_s_real": round(real_rows / dt_pad, 1), "gemm_routes": routes(requests * pad_to),
+                                                      "route": "the reference's right-padded [B, S] batch through the module path with the fused glue"},
+                                     "max_abs_ll_difference_between_routes": round(max(abs(a[0] - b[0]) for a, b in zip(res, res_pad)), 4),
+                                     "finite": bool(all(v[0] == v[0] for v in res)),
                                      "includes": "log_softmax over the continuation rows, gather + greedy flags on the device, sum(contlen) floats to the host (round 6; the reference ships [B, S, vocab] log-probabilities to the host, models_utils.py:331)"},
             "route": "set_fused_glue + onebit_attention_prefill (the config-3 prefill route)", "per": "GPU", "data": "synthetic"}
 

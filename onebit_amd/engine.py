@@ -608,21 +608,27 @@ class MixedStep:
         self._ws_off = (-self._ws.data_ptr()) % 256
         # one pinned staging row [tokens | row_slot | row_pos | out_rows] and ONE asynchronous copy per step; two of them in turn,
         # each guarded by an event, so that a caller who enqueues steps without synchronising never rewrites a row in flight
-        self._h_stage = [torch.zeros(3 * rows + ns, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._h_stage = [torch.zeros(4 * rows + ns, dtype=torch.int32).pin_memory() for _ in range(2)]
         self._h_np = [h.numpy() for h in self._h_stage]
         self._h_ev = [None, None]
-        self._d_stage = [torch.zeros(3 * rows + ns, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.next_tokens = torch.zeros(ns, dtype=torch.int32, device=dev)
-        if self.keep_logits:
-            self.logits = torch.zeros(ns, self.cfg.vocab_size, dtype=torch.float16, device=dev)
+        self._d_stage = [torch.zeros(4 * rows + ns, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.next_tokens = torch.zeros(rows + ns, dtype=torch.int32, device=dev)
         self._rows = rows
+        self._ensure_logits(ns)
+
+    def _ensure_logits(self, n: int):
+        if self.keep_logits and (self.logits is None or self.logits.shape[0] < n):
+            self.logits = None
+            self.logits = torch.zeros(max(n, self.n_slots), self.cfg.vocab_size, dtype=torch.float16, device=self.dev)
 
     @torch.no_grad()
     def launch(self, items) -> torch.Tensor:
         """Enqueue one step on the current stream.  ``items``: ``(slot, start, tokens)`` per scheduled request (distinct slots):
         ``tokens`` enter the request's cache slot at positions ``start ...``.  Returns the device tensor of greedy next tokens,
         one per item in the order given (the token after the item's LAST row: for a prompt chunk that is not the prompt's last one
-        the caller ignores it).  Asynchronous: synchronise before reading."""
+        the caller ignores it).  An item may carry a fourth element ``k`` (default 1): lm_head runs on its last ``k`` rows (the
+        evaluation caller scores a request's continuation rows) and the item contributes ``k`` consecutive entries to the returned
+        tokens and to ``logits``.  Asynchronous: synchronise before reading."""
         n_items = len(items)
         if n_items == 0 or n_items > self.n_slots:
             raise ValueError(f"MixedStep.launch: {n_items} items for {self.n_slots} slots")
@@ -635,10 +641,18 @@ class MixedStep:
         st = self._h_np[sb]
         tok, rs, rp, outr = st[:R], st[R:2 * R], st[2 * R:3 * R], st[3 * R:]
         order = sorted(range(n_items), key=lambda i: len(items[i][2]) != 1)          # single-token rows first (stable)
+        outs = [int(it[3]) if len(it) > 3 else 1 for it in items]
+        out0 = [0] * n_items
+        for i in range(1, n_items):
+            out0[i] = out0[i - 1] + outs[i - 1]
+        n_out = out0[-1] + outs[-1]
+        self._ensure_logits(n_out)
         segs, row, n_dec, dec_ctx, seen = [], 0, 0, 0, set()
         for i in order:
-            slot, start, toks = items[i]
+            slot, start, toks = items[i][:3]
             n = len(toks)
+            if not 1 <= outs[i] <= n:
+                raise ValueError(f"MixedStep.launch: item {i} asks for {outs[i]} output rows of {n}")
             if n < 1 or not 0 <= slot < ns or start < 0 or start + n > self.max_len or slot in seen:
                 raise ValueError(f"MixedStep.launch: item {i} (slot {slot}, start {start}, {n} tokens) outside the cache or a repeated slot")
             if min(toks) < 0 or max(toks) >= V:
@@ -652,7 +666,7 @@ class MixedStep:
                 dec_ctx = max(dec_ctx, start + 1)
             else:
                 segs.append((row, n, slot, start))
-            outr[i] = row + n - 1
+            outr[out0[i]:out0[i] + outs[i]] = range(row + n - outs[i], row + n)
             row += n
         d = self._d_stage[sb]
         d.copy_(self._h_stage[sb], non_blocking=True)                                # stream-ordered before the kernels
@@ -660,7 +674,7 @@ class MixedStep:
         self._h_ev[sb].record(torch.cuda.current_stream(self.dev))
         seg_arr = (_Seg * max(len(segs), 1))(*[_Seg(*g) for g in segs])
         base = d.data_ptr()
-        state = _MixedState(ctypes.sizeof(_MixedState), T, n_dec, len(segs), n_items, ns, self.attn_chunk, dec_ctx,
+        state = _MixedState(ctypes.sizeof(_MixedState), T, n_dec, len(segs), n_out, ns, self.attn_chunk, dec_ctx,
                             base, base + 4 * R, base + 8 * R, seg_arr, base + 12 * R, self.next_tokens.data_ptr(),
                             None if self.logits is None else self.logits.data_ptr(), self._part_val.data_ptr(), self._part_idx.data_ptr(),
                             self._ws.data_ptr() + self._ws_off, self._ws.numel() - self._ws_off)
@@ -668,4 +682,4 @@ class MixedStep:
             rc = self.lib.onebit_mixed_step(ctypes.byref(self._model), ctypes.byref(state), torch.cuda.current_stream(self.dev).cuda_stream)
         _lib.check(rc, "onebit_mixed_step")
         self.launches += 1
-        return self.next_tokens[:n_items]
+        return self.next_tokens[:n_out]

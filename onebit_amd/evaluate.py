@@ -82,17 +82,45 @@ def perplexity(model, token_ids: torch.Tensor, seqlen: int, limit: int = -1,
 
 
 @torch.no_grad()
+def _ragged_scorer(model, n_slots: int, max_len: int, any_dtype: bool = False):
+    """A ``MixedStep`` over ``n_slots`` fresh KV-cache slots for the ragged route of ``loglikelihood_tokens``; None when the
+    native step does not take the model (CPU, another model class, head_dim other than 64 / 128)."""
+    try:
+        from .engine import MixedStep, fp16_view
+        from .llama import KVCache, OneBitLlamaForCausalLM
+        if not isinstance(model, OneBitLlamaForCausalLM) or not model.lm_head.weight.is_cuda:
+            return None
+        if model.lm_head.weight.dtype != torch.float16 and not any_dtype:      # (an fp32 checkpoint keeps its fp32 logits unless asked)
+            return None
+        m16 = fp16_view(model)
+        cache = KVCache(m16.config, n_slots, max_len, m16.lm_head.weight.device, torch.float16)
+        return MixedStep(m16, cache.layers, n_slots, max_len, max_rows=64, keep_logits=True)
+    except (ValueError, ImportError):
+        return None
+
+
+@torch.no_grad()
 def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence[int]]], batch_size: int,
                          max_length: int, vocab_size: Optional[int] = None, rank: int = 0, world: int = 1,
-                         group=None) -> List[Tuple[float, bool]]:
+                         group=None, ragged: Optional[bool] = None, max_rows: int = 16384) -> List[Tuple[float, bool]]:
     """``[(sum log p(continuation | context), is_greedy)]`` for ``requests = [(context_ids,
     continuation_ids)]`` (models_utils.py:257-438).  ``vocab_size`` is the reference's
     ``[:, :, :self.vocab_size]`` slice (tokenizer vocabulary; default: all logits).
     ``world > 1``: chunk ``c`` of the sorted requests is evaluated by rank ``c % world``, the results are
-    exchanged with ``all_gather_object``; every rank returns the complete list."""
+    exchanged with ``all_gather_object``; every rank returns the complete list.
+    ``ragged`` (round 6; None = wherever the native step takes the model): a chunk runs as ONE ``onebit_mixed_step`` over the
+    requests' REAL token rows -- no right-padding to the longest request (the reference's batch of 32 requests of 44..390
+    tokens is 42 % padding), lm_head on the continuation rows only -- at most ``max_rows`` rows per call.  Causal attention
+    makes the padding irrelevant to the scored rows, so both routes score the same numbers up to fp16 GEMM-route noise."""
     if world < 1 or not 0 <= rank < world:
         raise ValueError("rank / world")
     dev = next(model.parameters()).device
+    scorer = None
+    if ragged is None or ragged:
+        longest = max((min(len(c) + len(t), max_length + 1) - 1 for c, t in requests), default=0)
+        scorer = _ragged_scorer(model, max(1, min(batch_size, len(requests))), max(longest, 1), any_dtype=bool(ragged)) if longest >= 1 else None
+        if ragged and scorer is None:
+            raise RuntimeError("loglikelihood_tokens(ragged=True): the native mixed step does not take this model / device")
     # Reorderer (models_utils.py:544-568): requests whose concatenated tokens are identical form ONE
     # group, evaluated once with the first member's (context, continuation) split -- the split is
     # not part of the key, a quirk kept here -- and groups are ordered by (-length, tokens).
@@ -118,17 +146,33 @@ def loglikelihood_tokens(model, requests: Sequence[Tuple[Sequence[int], Sequence
             inps.append(torch.cat([inp, torch.zeros(padding_length - inplen, dtype=torch.long)]).unsqueeze(0))
             inplens.append(inplen)
             conts.append(cont)
-        batched = torch.cat(inps, dim=0).to(dev)
-        logits = _model_logits(model, batched)                                  # [B, S, vocab] on the device
+        if scorer is not None:
+            # ragged route: items = (slot, 0, the request's input tokens, its continuation length); sub-batches of <= max_rows rows
+            lg, items, rows = [], [], 0
+            for b, (inp, n, c) in enumerate(zip(inps, inplens, conts)):
+                if items and rows + n > max_rows:
+                    scorer.launch(items)
+                    lg.append(scorer.logits[:sum(it[3] for it in items)].float())
+                    items, rows = [], 0
+                items.append((len(items), 0, inp[0, :n].tolist(), len(c)))
+                rows += n
+            scorer.launch(items)
+            lg.append(scorer.logits[:sum(it[3] for it in items)].float())
+            cont_rows = lg[0] if len(lg) == 1 else torch.cat(lg, dim=0)        # [sum(contlen), vocab], fp32 of the fp16 lm_head output
+        else:
+            batched = torch.cat(inps, dim=0).to(dev)
+            logits = _model_logits(model, batched)                              # [B, S, vocab] on the device
         # Score ON THE DEVICE (round 6).  The reference ships log_softmax of the whole [B, S, vocab] tensor to the host
         # (models_utils.py:331-334: 1.6 GB for a 32 x 389 batch of a 32000-word vocabulary) to read sum(contlen) numbers from it.
         # log_softmax is row-wise, so it is taken over the continuation rows [inplen - contlen, inplen) only -- the same values --,
         # the continuation's log-probabilities are gathered and the greedy flags formed there; the host receives sum(contlen)
         # floats + flags and adds each request's log-probabilities in the reference's order (fp32 on the CPU, :352).
-        b_idx = torch.tensor([b for b, (n, c) in enumerate(zip(inplens, conts)) for _ in c], dtype=torch.long, device=dev)
-        p_idx = torch.tensor([n - len(c) + j for n, c in zip(inplens, conts) for j in range(len(c))], dtype=torch.long, device=dev)
         cont_t = torch.tensor([t for c in conts for t in c], dtype=torch.long, device=dev)
-        lsm = F.log_softmax(logits[b_idx, p_idx], dim=-1)                        # [sum(contlen), vocab]
+        if scorer is None:
+            b_idx = torch.tensor([b for b, (n, c) in enumerate(zip(inplens, conts)) for _ in c], dtype=torch.long, device=dev)
+            p_idx = torch.tensor([n - len(c) + j for n, c in zip(inplens, conts) for j in range(len(c))], dtype=torch.long, device=dev)
+            cont_rows = logits[b_idx, p_idx]
+        lsm = F.log_softmax(cont_rows, dim=-1)                                   # [sum(contlen), vocab]
         if vocab_size is not None:
             lsm = lsm[:, :vocab_size]
         greedy_tok = (lsm.argmax(dim=-1) == cont_t).cpu()
