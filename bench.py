@@ -85,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--deadline", type=float, default=1500.0,
                     help="seconds after the headline measurement at which rank 0 prints the JSON line with whatever legs have finished "
                          "(field `incomplete`) and every rank exits: a hung secondary leg (a collective that never returns) cannot suppress the line")
-    ap.add_argument("--pg-timeout", type=float, default=120.0, help="process-group timeout in seconds (N > 1)")
+    ap.add_argument("--pg-timeout", type=float, default=300.0, help="process-group timeout in seconds (N > 1)")
     return ap.parse_args(argv)
 
 

@@ -68,6 +68,9 @@ OB_HIDDEN int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, 
 // the eligibility test of ob_gemm3_grouped alone (shapes, pitches, the weights' alignment, the GROUP's tile count against the CU count;
 // rows / outputs assumed 16-byte aligned): a caller that is about to choose between pre-scaled rows for the group and plain rows asks first
 OB_HIDDEN bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T);
+// 256 x 128 tiles of that launch (sum over the members) and the workgroup slots of one round (two workgroups per CU)
+OB_HIDDEN int64_t ob_gemm3_group_tiles(const onebit_proj_t *const *ps, int np, int64_t T);
+OB_HIDDEN int ob_gemm3_slots();
 // ONE projection on its pre-scaled rows a [T, K] as two to four K-slices in one launch of the LDS-DMA GEMM (fp32 sums z[i] [T, N], added and
 // scaled by the consuming row kernel): a hidden-width projection at a few hundred rows has too few 256 x 128 tiles for the chip (13B, 543 rows:
 // 100), its slices have that many times more.  ob_gemm3_ksplit_n: 0 when the projection alone is eligible for the LDS-DMA GEMM or no

@@ -1589,6 +1589,14 @@ bool ob_gemm3_group_ok(const onebit_proj_t *const *ps, int np, int64_t T)
     return tiles * std::max(grp_den, 1) >= (int64_t)ob_cu_count() && tiles <= 0x3fffffff;
 }
 
+int64_t ob_gemm3_group_tiles(const onebit_proj_t *const *ps, int np, int64_t T)
+{
+    int64_t tiles = 0;
+    for (int i = 0; i < np; ++i) tiles += ((ps[i]->N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);
+    return tiles;
+}
+int ob_gemm3_slots() { return 2 * ob_cu_count(); }
+
 int ob_gemm3_grouped(const onebit_proj_t *const *ps, void *const *us, const void *const *as, int np, int64_t T, hipStream_t s)
 {
     static const int env = getenv("OB_GEMM3_GROUPED") ? atoi(getenv("OB_GEMM3_GROUPED")) : 1;       // A/B: 0 = one launch per projection

@@ -301,6 +301,29 @@ extern "C" int onebit_mixed_step(const onebit_model_t *m, const onebit_mixed_sta
         }
         if (prescaled && T >= 192) {             // one grouped launch of the LDS-DMA GEMM: no partly filled last round per projection
             const void *av[3] = {as[0], as[np > 1 ? 1 : 0], as[np > 2 ? 2 : 0]};
+            // TAIL: when the last token tile (<= 128 rows) is what pushes the launch into one more round of workgroups (13B gate|up at 543
+            // rows: 540 tiles on 512 slots; a round costs ~100 us whatever its fill), the rows of that tile go through the skinny GEMM
+            // instead (one or two passes, ~30 us each) and the grouped launch covers whole rounds
+            static const int tail_env = getenv("OB_MIXED_TAIL") ? atoi(getenv("OB_MIXED_TAIL")) : 128;      // A/B: 0 = off; else the most tail rows
+            const int nbt = (T + 127) / 128, Tm = 128 * (nbt - 1), tail = T - Tm;
+            if (tail_env > 0 && tail >= 2 && tail <= tail_env && Tm >= 192 && ob_gemm3_group_ok(ps, np, Tm)) {
+                const int64_t slots = ob_gemm3_slots();
+                const int64_t r_all = (ob_gemm3_group_tiles(ps, np, T) + slots - 1) / slots, r_main = (ob_gemm3_group_tiles(ps, np, Tm) + slots - 1) / slots;
+                bool sk_ok = r_main < r_all;
+                for (int i = 0; sk_ok && i < np; ++i) sk_ok = ob_sk3_proj_ok(*ps[i]);
+                if (sk_ok && ob_gemm3_grouped(ps, us, av, np, Tm, s) == 0) {
+                    const int nblk = (tail + 63) / 64, rows = (tail + nblk - 1) / nblk;
+                    for (int r0 = Tm; r0 < T; r0 += rows) {
+                        const int n = std::min(rows, T - r0);
+                        void *ub[3] = {nullptr, nullptr, nullptr};
+                        const void *ab[3] = {nullptr, nullptr, nullptr};
+                        for (int i = 0; i < np; ++i) { ub[i] = (_Float16 *)us[i] + (size_t)r0 * ps[i]->N; ab[i] = as[i] + (size_t)r0 * ps[i]->K; }
+                        const int rc2 = ob_sk3_multi(ps, ub, ab, np, n, s);           // (n >= 2: tail >= 2, blocks balanced)
+                        if (rc2) return rc2;
+                    }
+                    return 0;
+                }
+            }
             if (ob_gemm3_grouped(ps, us, av, np, T, s) == 0) return 0;
         }
         if (prescaled && sk_pass) return sk_passes(ps, us, as, np);
