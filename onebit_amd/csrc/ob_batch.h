@@ -140,23 +140,57 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_b_norm_kernel(const ObBNorm
 // form (packed halves in registers, ONE shifted-sum reduction, v_fma_mixlo) instead of ob_layernorm_rows_kernel's fp32 copy of the row
 // and two reductions: the module path of a [16384, 4096] -> 11008 call 1.235 -> 1.208 ms (tools/module_prefill_probe.py).  In place (y == u) is fine: every thread reads its elements and the pivot before the
 // reduction's barrier and writes after it.
-template <int NV, bool BIAS>
-__global__ __launch_bounds__(OB_DEC_THREADS) void ob_ln_rows_kernel(const _Float16 *uin, const _Float16 *__restrict__ bias, _Float16 *y, int N, float eps)
+// ZIN: the rows arrive as up to four fp32 K-slice sums z0 .. z3 [T, N] of the LDS-DMA GEMM's K-sliced form (ob_gemm3_ksplit) and the weight
+// scale g: u = fp16(fp16(z0 + z1 + ..) * g) (bitnet.py:115-116) is formed here; `skip` (ONEBIT_FLAG_SKIP_LN) then writes u itself.
+struct ObLnRowsArgs {
+    const _Float16 *uin; const float *z[4]; const _Float16 *g, *bias; _Float16 *y;
+    int N, skip; float eps;
+};
+template <int NV, bool BIAS, bool ZIN = false>
+__global__ __launch_bounds__(OB_DEC_THREADS) void ob_ln_rows_kernel(const ObLnRowsArgs A)
 {
     __shared__ __attribute__((aligned(16))) float red[32];
-    const int tid = threadIdx.x;
-    const _Float16 *row = uin + (int64_t)blockIdx.x * N;
-    _Float16 *out = y + (int64_t)blockIdx.x * N;
+    const int tid = threadIdx.x, N = A.N;
+    const int64_t r0 = (int64_t)blockIdx.x * N;
+    _Float16 *out = A.y + r0;
     ob_half8 u[NV], bv[BIAS ? NV : 1];
     bool ok[NV];
+    auto zg8 = [&](int base) -> ob_half8 {
+        ob_float4 a = *reinterpret_cast<const ob_float4 *>(A.z[0] + r0 + base), b = *reinterpret_cast<const ob_float4 *>(A.z[0] + r0 + base + 4);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (A.z[j]) { a = a + *reinterpret_cast<const ob_float4 *>(A.z[j] + r0 + base); b = b + *reinterpret_cast<const ob_float4 *>(A.z[j] + r0 + base + 4); }
+        const ob_half8 gv = *reinterpret_cast<const ob_half8 *>(A.g + base);
+        ob_half8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = (_Float16)(ob_round_h(a[i]) * (float)gv[i]);
+            o[4 + i] = (_Float16)(ob_round_h(b[i]) * (float)gv[4 + i]);
+        }
+        return o;
+    };
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int base = (v * OB_DEC_THREADS + tid) * 8;
         ok[v] = base < N;
-        u[v] = *reinterpret_cast<const ob_half8 *>(row + (ok[v] ? base : 0));
-        if (BIAS) bv[v] = *reinterpret_cast<const ob_half8 *>(bias + (ok[v] ? base : 0));
+        if (ZIN) u[v] = zg8(ok[v] ? base : 0);
+        else u[v] = *reinterpret_cast<const ob_half8 *>(A.uin + r0 + (ok[v] ? base : 0));
+        if (BIAS) bv[v] = *reinterpret_cast<const ob_half8 *>(A.bias + (ok[v] ? base : 0));
     }
-    const float c0 = (float)row[0];
+    if (ZIN && A.skip) {                                     // (uniform) the pre-LayerNorm rows themselves
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (ok[v]) *reinterpret_cast<ob_half8 *>(out + (v * OB_DEC_THREADS + tid) * 8) = u[v];
+        return;
+    }
+    float c0;
+    if (ZIN) {
+        float z = A.z[0][r0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (A.z[j]) z += A.z[j][r0];
+        c0 = (float)(_Float16)(ob_round_h(z) * (float)A.g[0]);
+    } else c0 = (float)A.uin[r0];
     ob_float2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -164,7 +198,7 @@ __global__ __launch_bounds__(OB_DEC_THREADS) void ob_ln_rows_kernel(const _Float
     float st[2] = {s2[0] + s2[1], q2[0] + q2[1]};
     ob_block_sum_n<2, OB_DEC_WAVES>(st, red);
     float mean, rstd;
-    ob_ln_stats(st[0], st[1], c0, N, eps, mean, rstd);
+    ob_ln_stats(st[0], st[1], c0, N, A.eps, mean, rstd);
     const float nmr = -mean * rstd;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {

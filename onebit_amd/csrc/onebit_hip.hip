@@ -353,6 +353,26 @@ static void ob_launch_gemm3(const uint32_t *W, int64_t ldw_words, const _Float16
 
 // bytes a call cannot do without (F32: fp32 z is staged in y itself; F16 on the MFMA path: u is staged in
 // y; F16 shapes the MFMA path cannot take (K % 32 != 0) stage fp32 z in the workspace)
+template <bool ZIN>
+static void ob_launch_ln_rows(const ObLnRowsArgs &la, int64_t T, hipStream_t s)
+{
+    const int nv = (la.N + OB_DEC_THREADS * 8 - 1) / (OB_DEC_THREADS * 8);
+#define OB_LN_ROWS(NV_) do { if (la.bias) hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, true, ZIN>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, la); \
+                             else hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, false, ZIN>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, la); } while (0)
+    if (nv == 1) OB_LN_ROWS(1); else if (nv == 2) OB_LN_ROWS(2); else if (nv == 3) OB_LN_ROWS(3); else OB_LN_ROWS(4);
+#undef OB_LN_ROWS
+}
+
+static inline size_t ob_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+// shape part of ob_gemm3_ksplit_n's test (pointers unknown: onebit_linear_workspace_bytes)
+static bool ob_ksplit_shape_ok(int64_t T, int64_t K, int64_t N)
+{
+    onebit_proj_t p = {};
+    static const char dummy[16] __attribute__((aligned(16))) = {};
+    p.weight = dummy; p.weight_scale = dummy; p.input_factor = dummy; p.N = N; p.K = K; p.ldw_bytes = K / 8;
+    return K % 128 == 0 && N % 8 == 0 && N <= OB_DEC_MAXV * OB_DEC_THREADS * 8 && ob_gemm3_ksplit_n(p, T) > 0;
+}
+
 static size_t ob_required_workspace(int64_t T, int64_t K, int64_t N, int dtype)
 {
     if (T <= 0 || N <= 0) return 0;
@@ -366,6 +386,9 @@ extern "C" size_t onebit_linear_workspace_bytes(int64_t T, int64_t K, int64_t N,
     // large prefill calls run fastest with room for the pre-scaled activations a = fp16(x * h) (LDS-DMA
     // GEMM); a smaller or absent workspace is accepted and selects the register-staged kernel
     if (dtype == ONEBIT_F16 && K % 32 == 0 && ob_gemm3_ok(T, K, N)) return (size_t)T * (size_t)K * 2;
+    // a few hundred rows of a projection whose tiles alone leave the chip idle: room for the pre-scaled rows AND the fp32 sums of up to
+    // four K-slices (ob_gemm3_ksplit); without it such a call keeps the register-staged kernel
+    if (dtype == ONEBIT_F16 && ob_ksplit_shape_ok(T, K, N)) return ob_align256((size_t)T * (size_t)K * 2) + 4 * ob_align256((size_t)T * (size_t)N * 4);
     return ob_required_workspace(T, K, N, dtype);
 }
 
@@ -439,6 +462,36 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
             rc = ob_launch_status("linear_forward(gemm3)");
             if (rc) return rc;
         } else {
+            // K-sliced LDS-DMA GEMM (ob_gemm3_ksplit) when the caller's workspace has room for the pre-scaled rows and the slices' fp32 sums:
+            // scale pass, ns short rounds of workgroups in one launch, then ONE row pass that adds the slices, applies fp16(fp16(.) * g)
+            // and the LayerNorm -- whole call, 512 rows: 11008 -> 4096 132 -> 65 us, 4096 -> 4096 57 -> 44 us (tools/module_T_sweep.py)
+            onebit_proj_t pj = {};
+            pj.weight = packed; pj.input_factor = h; pj.weight_scale = g; pj.N = N; pj.K = K; pj.ldw_bytes = ldw_bytes;
+            const int ns = (!tile_stats && N % 8 == 0 && N <= OB_DEC_MAXV * OB_DEC_THREADS * 8 && (!bias || ob_aligned(bias, 16))) ? ob_gemm3_ksplit_n(pj, T) : 0;
+            const size_t a_bytes = ob_align256((size_t)T * (size_t)K * 2), z_bytes = ob_align256((size_t)T * (size_t)N * 4);
+            if (ns > 0 && workspace && ob_aligned(workspace, 256) && workspace_bytes >= a_bytes + (size_t)ns * z_bytes) {
+                const int64_t nvec = T * K / 8;
+                hipLaunchKernelGGL(ob_scale_rows_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const _Float16 *)x, K,
+                                   (const _Float16 *)h, (_Float16 *)workspace, T, (int)K);
+                float *zs[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int j = 0; j < ns; ++j) zs[j] = (float *)((char *)workspace + a_bytes + (size_t)j * z_bytes);
+                if ((rc = ob_gemm3_ksplit(pj, workspace, zs, ns, T, s))) return rc;
+                ObLnRowsArgs la = {};
+                for (int j = 0; j < ns; ++j) la.z[j] = zs[j];
+                la.g = (const _Float16 *)g; la.bias = skip ? nullptr : (const _Float16 *)bias; la.N = (int)N; la.eps = ln_eps;
+                if (u_or_null && !skip) {                       // both outputs wanted: u first, then y from it
+                    la.y = (_Float16 *)u_or_null; la.skip = 1;
+                    ob_launch_ln_rows<true>(la, T, s);
+                    ObLnRowsArgs lb = {};
+                    lb.uin = (const _Float16 *)u_or_null; lb.bias = (const _Float16 *)bias; lb.y = (_Float16 *)y; lb.N = (int)N; lb.eps = ln_eps;
+                    ob_launch_ln_rows<false>(lb, T, s);
+                } else {
+                    la.y = (_Float16 *)(skip ? ubuf : y); la.skip = skip;
+                    ob_launch_ln_rows<true>(la, T, s);
+                    if (skip && ubuf != y) (void)hipMemcpyAsync(y, ubuf, (size_t)T * N * 2, hipMemcpyDeviceToDevice, s);
+                }
+                return ob_launch_status("linear_forward(k-sliced)");
+            }
             ob_launch_mm16<false>(packed, ldw_bytes, x, K, h, g, ubuf, nullptr, T, K, N, s);
             rc = ob_launch_status("linear_forward(mm16)");
             if (rc) return rc;
@@ -449,12 +502,9 @@ extern "C" int onebit_linear_forward(const void *packed, int64_t ldw_bytes, cons
         if (skip && ubuf == y) return 0;
         static const int ln_v3 = getenv("OB_LN_ROWS") ? atoi(getenv("OB_LN_ROWS")) : 1;           // A/B: 0 = ob_layernorm_rows_kernel
         if (ln_v3 && !skip && T >= 64 && N % 8 == 0 && N <= OB_DEC_MAXV * OB_DEC_THREADS * 8 && ob_aligned(ubuf, 16) && (!bias || ob_aligned(bias, 16))) {
-            const _Float16 *ui = (const _Float16 *)ubuf, *bi = (const _Float16 *)bias;
-            const int nv = (int)((N + OB_DEC_THREADS * 8 - 1) / (OB_DEC_THREADS * 8));
-#define OB_LN_ROWS(NV_) do { if (bi) hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, true>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, ui, bi, (_Float16 *)y, (int)N, ln_eps); \
-                             else hipLaunchKernelGGL((ob_ln_rows_kernel<NV_, false>), dim3((unsigned)T), dim3(OB_DEC_THREADS), 0, s, ui, bi, (_Float16 *)y, (int)N, ln_eps); } while (0)
-            if (nv == 1) OB_LN_ROWS(1); else if (nv == 2) OB_LN_ROWS(2); else if (nv == 3) OB_LN_ROWS(3); else OB_LN_ROWS(4);
-#undef OB_LN_ROWS
+            ObLnRowsArgs la = {};
+            la.uin = (const _Float16 *)ubuf; la.bias = (const _Float16 *)bias; la.y = (_Float16 *)y; la.N = (int)N; la.eps = ln_eps;
+            ob_launch_ln_rows<false>(la, T, s);
             return ob_launch_status("linear_forward(layernorm rows)");
         }
         ob_launch_ln_f16<false>(nullptr, (const _Float16 *)ubuf, (const _Float16 *)g, (const _Float16 *)bias,
