@@ -1691,7 +1691,8 @@ int ob_gemm3_ksplit_n(const onebit_proj_t &p, int64_t T)
     static const int env3 = getenv("OB_GEMM3") ? atoi(getenv("OB_GEMM3")) : 1;
     // a projection with fewer tiles than this is sliced (default: what the unsliced LDS-DMA GEMM asks for, two thirds of the CUs)
     static const int tiles_env = getenv("OB_GEMM3_KSPLIT_TILES") ? atoi(getenv("OB_GEMM3_KSPLIT_TILES")) : 0;
-    if (env < 2 || !env3 || T < 192 || p.K % (4 * OB_G2_K) != 0 || p.N % 4 != 0 || T * p.K * 2 >= ((int64_t)1 << 32) || p.ldw_bytes % 16 != 0 ||
+    static const int tmin = getenv("OB_GEMM3_KSPLIT_TMIN") ? atoi(getenv("OB_GEMM3_KSPLIT_TMIN")) : 65;
+    if (env < 2 || !env3 || T < tmin || p.K % (4 * OB_G2_K) != 0 || p.N % 4 != 0 || T * p.K * 2 >= ((int64_t)1 << 32) || p.ldw_bytes % 16 != 0 ||
         p.N * p.ldw_bytes >= ((int64_t)1 << 32) || !p.weight || !p.weight_scale || !ob_aligned(p.weight, 16) || !ob_aligned(p.weight_scale, 16))
         return 0;
     const int64_t tiles = ((p.N + OB_G2_N - 1) / OB_G2_N) * ((T + 127) / 128);

@@ -120,6 +120,7 @@ KSLICED = [
     ((300,), 4096, 4096, True),       # 4 slices of 1024 columns, bias
     ((2, 257), 2816, 1000, False),    # 11 quads -> 2 slices (6 + 5), ragged token tile, N % 256 != 0
     ((200,), 11008, 4096, False),     # 43 quads -> 4 slices (11 + 11 + 11 + 10)
+    ((70,), 4096, 4096, False),       # one token tile, 55 % full
 ]
 
 
