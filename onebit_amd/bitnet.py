@@ -33,7 +33,15 @@ def _dtype_code(dtype: torch.dtype) -> int:
     raise TypeError(f"OneBit HIP kernels support float16 and float32 parameters, got {dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device: torch.device) -> int:
+    """The current HIP stream of ``device`` as an integer handle (the raw accessor torch's own launchers use: 0.3 us instead of
+    the 4 us of building a torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -185,55 +193,83 @@ class BitLinearInf(nn.Module):
         return self.forward(a, _pre_ln=True, _prescaled=True)
 
     def forward(self, input: torch.Tensor, _pre_ln: bool = False, _prescaled: bool = False) -> torch.Tensor:
+        # (Host cost matters here: the reference's model code calls this 224 times per decoded token and the kernels behind a
+        #  single-token call take ~10 us.  Parameters are read from _parameters directly -- nn.Module.__getattr__ costs 0.2 us per
+        #  access --, the device guard is taken only when the input lives on another device than the current one, the stream comes
+        #  from the raw-stream accessor: 25.4 -> 14.9 us per call at T = 1, tools/module_overhead_probe.py.)
         K, N = self.in_features, self.out_features
         if input.shape[-1] != K:
             raise RuntimeError(f"BitLinearInf: expected last dim {K}, got {tuple(input.shape)}")
+        prm = self._parameters
+        w, h, g, b = prm.get("weight"), prm.get("input_factor"), prm.get("weight_scale"), prm.get("bias")
+        if w is None or h is None or g is None:                # (someone re-registered them as buffers / plain attributes)
+            w, h, g, b = self.weight, self.input_factor, self.weight_scale, self.bias
         _require_gpu(input, "BitLinearInf.forward")
-        _require_gpu(self.weight, "BitLinearInf.forward (parameters)")
-        pdt = self.weight_scale.dtype
+        _require_gpu(w, "BitLinearInf.forward (parameters)")
+        pdt = g.dtype
         # bitnet.py:113 multiplies input by input_factor (type promotion), :115 then needs the
         # product to have the dtype of the unpacked weight (= weight_scale.dtype).
-        cdt = torch.promote_types(input.dtype, self.input_factor.dtype)
+        cdt = input.dtype if input.dtype == h.dtype else torch.promote_types(input.dtype, h.dtype)
         if cdt != pdt:
             raise RuntimeError(
                 f"BitLinearInf: input dtype {input.dtype} with parameters of dtype {pdt} "
                 f"(the reference's F.linear raises on this mix as well)")
         code = _dtype_code(cdt)
-        if _pre_ln or isinstance(self.layernorm, nn.Identity):
+        ln = self._modules.get("layernorm")
+        if _pre_ln or isinstance(ln, nn.Identity):
             flags, eps = _lib.FLAG_SKIP_LN, 0.0
-        elif isinstance(self.layernorm, nn.LayerNorm) and not self.layernorm.elementwise_affine:
-            flags, eps = 0, float(self.layernorm.eps)
+        elif isinstance(ln, nn.LayerNorm) and not ln.elementwise_affine:
+            flags, eps = 0, float(ln.eps)
         else:
             raise RuntimeError("BitLinearInf.layernorm must be the parameter-free LayerNorm or nn.Identity")
 
-        x = input.to(cdt).reshape(-1, K)
+        x = input if input.dtype == cdt else input.to(cdt)
+        x = x.reshape(-1, K)
         if not x.is_contiguous():
             x = x.contiguous()
         T = x.shape[0]
-        w = self.weight
         if w.dim() != 2 or w.shape[0] != N or w.shape[1] != K // 8 or w.dtype not in (torch.int8, torch.uint8):
             raise RuntimeError(f"BitLinearInf.weight must be int8 [{N}, {K // 8}], got {w.dtype} {tuple(w.shape)}")
         if w.stride(1) != 1:
             w = w.contiguous()
-        h = self.input_factor.contiguous()
-        g = self.weight_scale.contiguous()
-        b = None if self.bias is None else self.bias.to(cdt).contiguous()
-        y = torch.empty((T, N), dtype=cdt, device=x.device)
+        if not h.is_contiguous():
+            h = h.contiguous()
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if b is not None:
+            b = b.to(cdt).contiguous()
+        dev = x.device
+        y = torch.empty((T, N), dtype=cdt, device=dev)
         lib = _lib.load()
-        if _prescaled:
-            flags |= _lib.FLAG_PRESCALED
-            ws_bytes = 0                                   # the scaled rows ARE the input
-        else:
-            with torch.cuda.device(x.device):
-                ws_bytes = lib.onebit_linear_workspace_bytes(T, K, N, code)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
-        with torch.cuda.device(x.device):
+        guard = None
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            guard = torch.cuda.device(dev)
+            guard.__enter__()
+        try:
+            if _prescaled:
+                flags |= _lib.FLAG_PRESCALED
+                ws_bytes = 0                                   # the scaled rows ARE the input
+            else:
+                cache = self.__dict__.get("_ws_bytes")
+                if cache is None:
+                    cache = self.__dict__["_ws_bytes"] = {}
+                key = (T, code, dev.index)
+                ws_bytes = cache.get(key)
+                if ws_bytes is None:                           # (depends on the shape and the device's CU count only)
+                    if len(cache) > 256:
+                        cache.clear()
+                    ws_bytes = cache[key] = int(lib.onebit_linear_workspace_bytes(T, K, N, code))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
             rc = lib.onebit_linear_forward(
                 w.data_ptr(), w.stride(0), x.data_ptr(), h.data_ptr(), g.data_ptr(),
                 None if b is None else b.data_ptr(), y.data_ptr(), None,
                 None if ws is None else ws.data_ptr(), ws_bytes,
-                T, K, N, code, eps, flags, _stream_ptr(x.device))
-        _lib.check(rc, "onebit_linear_forward")
+                T, K, N, code, eps, flags, _stream_ptr(dev))
+        finally:
+            if guard is not None:
+                guard.__exit__(None, None, None)
+        if rc:
+            _lib.check(rc, "onebit_linear_forward")
         return y.view(*input.shape[:-1], N)
 
 
