@@ -177,12 +177,27 @@ class BitLinearInf(nn.Module):
     def prescaled_ok(self, T: int, dtype=torch.float16, bias_deferred: bool = False) -> bool:
         """True when a T-row call of this layer may consume pre-scaled activations
         (``pre_layernorm_prescaled``): it takes the LDS-DMA GEMM, which reads fp16(x * h) rows."""
-        if (self.bias is not None and not bias_deferred) or dtype != torch.float16 or self.weight_scale.dtype != torch.float16:
+        prm = self._parameters
+        w, g, b = prm.get("weight"), prm.get("weight_scale"), prm.get("bias")
+        if w is None or g is None:
+            w, g, b = self.weight, self.weight_scale, self.bias
+        if (b is not None and not bias_deferred) or dtype != torch.float16 or g.dtype != torch.float16:
             return False
-        if not self.weight.is_cuda or self.weight.stride(-1) != 1 or self.weight.stride(0) % 16 or self.weight.data_ptr() % 16:
+        if not w.is_cuda or w.stride(-1) != 1 or w.stride(0) % 16 or w.data_ptr() % 16:
             return False                                   # what the C side requires of the packed rows for the flag
-        with torch.cuda.device(self.weight.device):        # eligibility depends on the CU count of the device that will run it
-            return bool(_lib.load().onebit_linear_prescaled_ok(T, self.in_features, self.out_features, _dtype_code(dtype)))
+        # (asked once per projection and forward by the fused prompt pass: 221 ctypes calls + device guards per 7B forward, 2 ms of
+        #  its 6.3 ms host time, before the answer was cached per row count and device)
+        cache = self.__dict__.get("_pres_ok")
+        if cache is None:
+            cache = self.__dict__["_pres_ok"] = {}
+        key = (T, w.device.index)
+        ok = cache.get(key)
+        if ok is None:
+            if len(cache) > 256:
+                cache.clear()
+            with torch.cuda.device(w.device):              # eligibility depends on the CU count of the device that will run it
+                ok = cache[key] = bool(_lib.load().onebit_linear_prescaled_ok(T, self.in_features, self.out_features, _dtype_code(dtype)))
+        return ok
 
     def pre_layernorm_prescaled(self, a: torch.Tensor) -> torch.Tensor:
         """``pre_layernorm`` on activations the producer already scaled: ``a = fp16(x * input_factor)``
