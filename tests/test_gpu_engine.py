@@ -534,6 +534,7 @@ def test_attn_blind_hint_does_not_change_results():
           max_position_embeddings=512), 333, 128),
     (dict(vocab_size=512, hidden_size=512, intermediate_size=1536, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=256,
           attention_bias=True), 1, 2048),
+    (dict(vocab_size=512, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=512), 129, 64),
 ])
 def test_engine_prime_is_the_native_prefill(golden_dir, cfgkw, S, rows):
     """DecodeEngine.prime (round 6): the prompt through onebit_mixed_step -- whole, in chunks of `rows` tokens (64 / 128: chunks with past),
