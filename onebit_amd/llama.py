@@ -467,6 +467,64 @@ class OneBitLlamaForCausalLM(nn.Module):
         return torch.cat(out, dim=1)
 
 
+def _generate_native(self, input_ids: torch.Tensor, max_new_tokens: int, eos_token_id=None, pad_token_id=None) -> torch.Tensor:
+    """``generate`` on the native engines, same return contract: B = 1 -> ``DecodeEngine`` (the prompt through ``onebit_mixed_step``,
+    every further token one HIP-graph replay of ``onebit_decode_step``); B > 1 -> ``ContinuousBatcher`` with one slot per row (the
+    prompts enter in ONE mixed step, decode-only steps replay the batched step's graph).  The steps are enqueued without looking at
+    the tokens; EOS is applied afterwards exactly as ``generate`` applies it (a finished row continues with ``pad_token_id``, the
+    output ends where every row is finished: generation/utils.py:2543-2570).  Engines are kept per (batch, max_len) on the model.
+    Greedy tokens equal ``generate``'s up to fp16 near-ties of the logits (the engines' kernels sum in another order)."""
+    from .engine import DecodeEngine
+    from .serving import ContinuousBatcher
+    if input_ids.dim() != 2:
+        raise ValueError("input_ids must be [B, S]")
+    B, S = input_ids.shape
+    if max_new_tokens < 1:
+        return input_ids
+    eos = None
+    if eos_token_id is not None:
+        eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
+        if pad_token_id is None:
+            if B > 1:
+                raise ValueError("generate: eos_token_id with batch > 1 needs pad_token_id (generation/utils.py:2543)")
+            pad_token_id = next(iter(eos)) if not isinstance(eos_token_id, (list, tuple)) else int(eos_token_id[0])
+    dev = self.lm_head.weight.device
+    engines = self.__dict__.setdefault("_native_engines", {})
+    max_len = S + max_new_tokens
+    key = (B, -(-max_len // 256) * 256)
+    if key[1] > self.config.max_position_embeddings:
+        key = (B, self.config.max_position_embeddings)
+    if max_len > key[1]:
+        raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+    if B == 1:
+        eng = engines.get(key)
+        if eng is None:
+            if len(engines) >= 4:
+                engines.clear()
+            eng = engines[key] = DecodeEngine(self, max_len=key[1])
+        rows = [eng.generate(input_ids, max_new_tokens)[0, S:].tolist()]
+    else:
+        cb = engines.get(key)
+        if cb is None:
+            if len(engines) >= 4:
+                engines.clear()
+            cb = engines[key] = ContinuousBatcher(self, max_batch=B, max_len=key[1])
+        ids = [cb.add_request(r, max_new_tokens) for r in input_ids.tolist()]
+        out = cb.run()
+        rows = [out[i] for i in ids]
+        for i in ids:
+            cb.sched.finished.pop(i, None)
+    if eos is not None:
+        ends = [next((j + 1 for j, t in enumerate(r) if t in eos), len(r)) for r in rows]
+        n = max(ends)
+        rows = [r[:e] + [pad_token_id] * (n - e) for r, e in zip(rows, ends)]
+    new = torch.tensor(rows, dtype=input_ids.dtype, device=dev)
+    return torch.cat([input_ids.to(dev), new], dim=1)
+
+
+OneBitLlamaForCausalLM.generate_native = torch.no_grad()(_generate_native)
+
+
 def synthetic_state_dict(config: OneBitLlamaConfig, seed: int = 0, dtype=torch.float16, device="cpu"):
     """Seeded synthetic OneBit checkpoint in the reference's on-disk key layout (SURVEY.md 3.4 /
     8d): packed W = uniform random bytes, h, g = 0.1*U(0.5,1.5) with 10% sign flips, RMSNorm = 1,

@@ -566,3 +566,36 @@ def test_engine_prime_is_the_native_prefill(golden_dir, cfgkw, S, rows):
         j = next(i for i in range(10) if got[i] != ref[i])
         l2 = model(torch.tensor([ids[0].tolist() + ref[:j]], device=dev))[0, -1].float()
         assert abs(float(l2[got[j]] - l2[ref[j]])) < 2e-2 * float(l2.abs().max()), (j, got, ref)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_generate_native_keeps_generates_contract(B):
+    """OneBitLlamaForCausalLM.generate_native (DecodeEngine for B = 1, ContinuousBatcher for B > 1) against generate (module path):
+    the same [B, S + n] tensor -- tokens equal up to a near-tie of the module path's logits --, with an EOS token that really occurs:
+    rows end at their first EOS, continue with pad_token_id, the output ends where the last row ends."""
+    from onebit_amd.llama import OneBitLlamaConfig, build_synthetic_model
+    dev = torch.device("cuda:0")
+    cfg = OneBitLlamaConfig(vocab_size=64, hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4,
+                            max_position_embeddings=256)
+    model = build_synthetic_model(cfg, seed=23, device=dev)
+    ids = torch.randint(0, cfg.vocab_size, (B, 9), generator=torch.Generator().manual_seed(B)).to(dev)
+    ref = model.generate(ids, 24)
+    got = model.generate_native(ids, 24)
+    assert got.shape == ref.shape and torch.equal(got[:, :9], ids)
+
+    def same_or_near_tie(a, b):
+        for r in range(B):
+            ra, rb = a[r].tolist(), b[r].tolist()
+            if ra != rb:
+                j = next(i for i in range(len(ra)) if ra[i] != rb[i])
+                lg = model(torch.tensor([rb[:j]], device=dev))[0, -1].float()
+                assert abs(float(lg[ra[j]] - lg[rb[j]])) < 2e-2 * float(lg.abs().max()), (r, j)
+                return False
+        return True
+    if same_or_near_tie(got, ref):
+        eos = int(ref[0, 9 + 5])                                   # a token the first row really produces
+        ref_e = model.generate(ids, 24, eos_token_id=eos, pad_token_id=0)
+        got_e = model.generate_native(ids, 24, eos_token_id=eos, pad_token_id=0)
+        assert torch.equal(got_e, ref_e)
+        assert ref_e.shape[1] <= ref.shape[1] and (B > 1 or int(ref_e[0, -1]) == eos)
+    assert len(model._native_engines) == 1                        # the engine is kept for the next call
