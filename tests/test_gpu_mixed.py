@@ -486,3 +486,14 @@ def test_mixed_step_full_size_properties():
     srt = ref.sort().values
     if float(srt[-1] - srt[-2]) > 2e-2 * float(ref.abs().max()):
         assert int(n4[0]) == int(n1[24])
+
+
+def test_mixed_step_randomised_mixes():
+    """tools/mixed_fuzz.py, short form: random mixes of decoding slots and prompt chunks whose row counts cross every route threshold
+    (one skinny launch / passes / grouped GEMM with or without a skinny tail / K-slices), five model shapes incl. GQA, attention_bias,
+    7B and 13B widths: every item's logits and greedy token against the module path on the item's whole history."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mixed_fuzz.py"), "5", "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
