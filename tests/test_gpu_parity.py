@@ -179,6 +179,40 @@ def test_forward_fp16_k_sliced_route_vs_oracle(dev, coracle, lead, K, N, bias):
     assert np.abs(y - y_ref).max() <= 2.5 * FP16_ULP * max(1.0, float(np.abs(y_ref).max()))
 
 
+def test_forward_random_mid_size_shapes_vs_oracle(dev, coracle):
+    """Seeded random (T, K, N) in the band where round 6 changed the routing of onebit_linear_forward (65 .. 641 rows; K-sliced GEMM with
+    2 .. 4 slices, the LDS-DMA GEMM from its tile threshold on, ragged token / row tiles, N % 256 != 0, bias) against the oracle; bars as in
+    test_forward_fp16_k_sliced_route_vs_oracle."""
+    rng = np.random.default_rng(20260101)
+    for case in range(7):               # (the oracle's time bounds the case count: ~8 s each)
+        K = int(rng.choice([2048, 2816, 4096, 5632, 1024, 3072]))
+        N = int(rng.integers(16, 300)) * 8
+        T = int(rng.choice([65, 70, 128, 129, 191, 192, 200, 257, 320, 384, 500, 641]))
+        bias = bool(rng.integers(0, 2))
+        packed = rng.integers(0, 256, (N, K // 8), dtype=np.uint8).view(np.int8)
+        x = rng.standard_normal((T, K)).astype(np.float16)
+        flip = lambda n: np.where(rng.random(n) < 0.1, -1.0, 1.0)
+        h = (0.1 * (0.5 + rng.random(K)) * flip(K)).astype(np.float16)
+        g = (0.1 * (0.5 + rng.random(N)) * flip(N)).astype(np.float16)
+        b = (0.1 * rng.standard_normal(N)).astype(np.float16) if bias else None
+        y_ref, u_ref = coracle.forward_f16(packed, x, h, g, b, return_pre_ln=True)
+        m = _make_layer(K, N, torch.float16, dev, packed, h, g, b)
+        xt = _t(x, dev)
+        y = m(xt).cpu().numpy().astype(np.float32)
+        m.layernorm = torch.nn.Identity()
+        m.bias = None
+        u = m(xt).cpu().numpy().astype(np.float32)
+        y_ref, u_ref = np.asarray(y_ref, np.float32), np.asarray(u_ref, np.float32)
+        tag = (case, T, K, N, bias)
+        floor = np.abs(u_ref).max(axis=1, keepdims=True) * 2.0 ** -9
+        bad = np.abs(u - u_ref) > 2.001 * np.maximum(np.abs(u_ref), floor) * FP16_ULP
+        assert not bad.any(), (tag, int(bad.sum()))
+        assert (u != u_ref).mean() <= 0.02, tag
+        rel = np.linalg.norm(y - y_ref) / (np.linalg.norm(y_ref) + 1e-30)
+        assert rel <= 1e-3, (tag, rel)
+        assert np.abs(y - y_ref).max() <= 2.5 * FP16_ULP * max(1.0, float(np.abs(y_ref).max())), tag
+
+
 @pytest.mark.parametrize("lead,K,N,bias", [((2,), 256, 80, True), ((1,), 4096, 512, False), ((3,), 40, 9, False)])
 def test_forward_fp32_vs_oracle(dev, coracle, lead, K, N, bias):
     rng = np.random.default_rng(K + N)
