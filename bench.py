@@ -309,6 +309,17 @@ def measure_prefill_sharded(cfg, dev, world, rank):
     except Exception as e:
         res["n_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
     res["token_sharded"] = entry(dt2, dmin2, tokens_per_rank=Tl)
+    # context, not a baseline the metric names: the vendor library's DENSE fp16 GEMM of the same shape on already-unpacked weights (what the
+    # reference's forward costs after its unpack), timed the same way in the same process
+    try:
+        wd = torch.randn(N, K, generator=g, device=dev).half()
+        yd = torch.empty(Tl, N, device=dev, dtype=torch.float16)
+        dt4, dmin4 = _timed(lambda: torch.matmul(xl, wd.t(), out=yd), dev, world)
+        res["vendor_dense_fp16_gemm"] = entry(dt4, dmin4, tokens_per_rank=Tl, what="torch.matmul (hipBLASLt / rocBLAS) on dense fp16 weights, no scales, no LayerNorm",
+                                              sustained="profiles/r06_dense_vs_onebit_power.txt: 1273 TFLOP/s at 1.84 GHz against 1481 for the 1-bit GEMM alone, both at the 1.4 kW limit")
+        del wd, yd
+    except Exception as e:
+        res["vendor_dense_fp16_gemm"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 
