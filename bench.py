@@ -510,6 +510,28 @@ def measure_mixed_step(model, dev, slots=32, n_prefill=8, prompt=512, ctx=128, i
             "onebit_layer_TFLOPs_equivalent": round(2.0 * rows * w1 / med / 1e9, 1),
             "launches_per_layer": "norm, q|k|v (one grouped GEMM), rope / append, flash (prompt chunks), key-block (decode rows), o, norm, gate|up (grouped), swiglu, down = 10",
             "engine": "onebit_mixed_step"}
+    # (a2) chunked prefill with a small step budget: ONE prompt chunk of 64 / 256 / 512 tokens next to slots - 1 decoding requests -- the
+    # steps a latency-minded scheduler issues (routes: passes of the skinny GEMM / grouped GEMM + K-sliced o, down / + skinny tail)
+    mid = []
+    if requests >= 32:                             # (the probes under tools/ that profile ONE step shape pass a short stream)
+        nd = slots - 1
+        ms.launch([(s, 0, rnd(ctx)) for s in range(nd)])
+        for chunk in (64, 256, 512):
+            if chunk > prompt:
+                continue
+            it2 = [(s, ctx, rnd(1)) for s in range(nd)] + [(nd, 0, rnd(chunk))]
+            for _ in range(2):
+                ms.launch(it2)
+            torch.cuda.synchronize(dev)
+            e2 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            e2[0].record()
+            for i in range(4):
+                ms.launch(it2)
+                e2[i + 1].record()
+            torch.cuda.synchronize(dev)
+            t2 = sorted(e2[i].elapsed_time(e2[i + 1]) for i in range(4))
+            mid.append({"rows": nd + chunk, "decode_rows": nd, "prompt_chunk": chunk, "ms": round(t2[1], 3), "tokens_per_s": round((nd + chunk) / t2[1] * 1e3, 1)})
+    step["mid_size_steps"] = mid
     del ms, caches
     torch.cuda.empty_cache()
     # (b) the request stream
